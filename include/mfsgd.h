@@ -1,0 +1,140 @@
+/* mfsgd.h - C-ABI of libmfsgd.so: the MI355X (gfx950) blocked-SGD matrix-factorization path.
+ *
+ * The reference (dtrager02/Recommender) is pure Python and has no FFI layer; its boundary for this
+ * path is the set of Python callables listed in SURVEY.md section 8(b).  Each entry point below
+ * names the reference callable it replaces (paths under /root/reference).  The Python mirror of
+ * those callables (recommender_amd/ *.py) binds exactly these symbols through ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; mfsgd_last_error() (thread-local) says why;
+ *  - every array pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) unless the
+ *    parameter name starts with h_; the library never frees or reallocates caller arrays;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on
+ *    that stream unless the name ends in _sync or the comment says it synchronises;
+ *  - samples are int32 [n][stride] row-major, columns 0,1,2 = user,item,rating (Recommender.py:54);
+ *  - T is float (f32) or double (f64); factor matrices are row-major [rows][k];
+ *  - implicit: 0 = none (biased MF), 1 = frozen (y read-only through z = sum(y[N(u)])/sqrt|N(u)|),
+ *              2 = full (SVD++: y rewritten for all of N(u) on every rating, numba_methods.py:23);
+ *  - variant:  0 = numba_methods.sgd order (numba_methods.py:11-23), 1 = sgd2 order (:31-55).
+ *  There is no CPU fallback: every entry point fails with an error when no gfx950 device is present.
+ */
+#ifndef MFSGD_H
+#define MFSGD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFSGD_OK 0
+#define MFSGD_ERR_ARG (-1)
+#define MFSGD_ERR_HIP (-2)
+#define MFSGD_ERR_UNSUPPORTED (-3)
+#define MFSGD_ERR_GRID (-4)
+
+const char *mfsgd_last_error(void);
+int mfsgd_version(void);
+/* number of visible devices (>=1) or <0; checks that the current device is gfx950 */
+int mfsgd_device_check(void);
+
+/* ---- update kernels: replace numba_methods.sgd / sgd2 (numba_methods.py:7-57) and the block-local
+ * sgd (RayBlockScheduler.py:118-145).  One exact-order sequential pass over `samples`:
+ * results equal the reference's loop order rating by rating.  u_off/i_off are the block offsets of
+ * the block-local form (P,Q,b_u,b_i are then the slices; y,row_ptrs,col_inds stay global); 0,0 for
+ * the global form.  y may be NULL iff implicit==0; z may be NULL (then the implicit term is gathered
+ * from y through row_ptrs/col_inds on every rating, as the reference does). */
+int mfsgd_hip_sgd_f32(float *P, float *Q, float *b_u, float *b_i, float b, float *y, const float *z,
+                      const int32_t *samples, int64_t n, int32_t stride,
+                      const int64_t *row_ptrs, const int32_t *col_inds,
+                      int32_t k, int32_t u_off, int32_t i_off,
+                      float alpha, float beta1, float beta2, int32_t variant, int32_t implicit, void *stream);
+int mfsgd_hip_sgd_f64(double *P, double *Q, double *b_u, double *b_i, double b, double *y, const double *z,
+                      const int32_t *samples, int64_t n, int32_t stride,
+                      const int64_t *row_ptrs, const int32_t *col_inds,
+                      int32_t k, int32_t u_off, int32_t i_off,
+                      double alpha, double beta1, double beta2, int32_t variant, int32_t implicit, void *stream);
+
+/* ---- RMSE: replaces numba_methods.mse2 / mse (numba_methods.py:59-103) with the exact (all rows)
+ * evaluation of the :94-100 predictor.  Writes the SUM of squared errors (double) to *d_sse; the
+ * caller takes sqrt(sse/n).  d_partials: device scratch of mfsgd_rmse_partials(n) doubles.
+ * Deterministic (fixed reduction order). */
+int64_t mfsgd_rmse_partials(int64_t n);
+int mfsgd_hip_rmse_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
+                       const float *y, const float *z, const int32_t *samples, int64_t n, int32_t stride,
+                       const int64_t *row_ptrs, const int32_t *col_inds, int32_t k, int32_t implicit,
+                       double *d_partials, double *d_sse, void *stream);
+int mfsgd_hip_rmse_f64(const double *P, const double *Q, const double *b_u, const double *b_i, double b,
+                       const double *y, const double *z, const int32_t *samples, int64_t n, int32_t stride,
+                       const int64_t *row_ptrs, const int32_t *col_inds, int32_t k, int32_t implicit,
+                       double *d_partials, double *d_sse, void *stream);
+
+/* z[u] = sum_{j in N(u)} y[j] / (sqrt|N(u)| + plus_one)  (numba_methods.py:14-16, :36 for plus_one=1) */
+int mfsgd_hip_implicit_z_f32(const float *y, const int64_t *row_ptrs, const int32_t *col_inds,
+                             int64_t n_users, int32_t k, int32_t plus_one, float *z, void *stream);
+int mfsgd_hip_implicit_z_f64(const double *y, const int64_t *row_ptrs, const int32_t *col_inds,
+                             int64_t n_users, int32_t k, int32_t plus_one, double *z, void *stream);
+
+/* ---- data prep (integer work, bit-exact with the reference).  These calls allocate and free
+ * device temporaries and synchronise the stream before returning.
+ * remap: ExplicitMF.random_renumber_samples id remap (SGDRecommender.py:251-256), in place. */
+int mfsgd_hip_remap(int32_t *samples, int64_t n, int32_t stride, const int32_t *row_perm,
+                    const int32_t *col_perm, int64_t n_users, int64_t n_items, void *stream);
+/* filter_test: drop test rows whose user or item is absent from train (SGDRecommender.py:259-263).
+ * Stable; writes kept rows to out[][stride] and their count to *h_count (host). */
+int mfsgd_hip_filter_test(const int32_t *test, int64_t nt, int32_t stride, const int32_t *train, int64_t n,
+                          int32_t tstride, int64_t n_users, int64_t n_items, int32_t *out, int64_t *h_count,
+                          void *stream);
+/* bucket: ExplicitMF.generate_indpendent_samples_new (SGDRecommender.py:187-212): block (r,c) = rows
+ * with user/ubp==r and item/ibp==c in original relative order; blocks concatenated row-major into
+ * out_samples[n][3]; out_block_ptr[Pu*Pi+1].  Fails if a row falls outside the Pu x Pi grid. */
+int mfsgd_hip_bucket(const int32_t *samples, int64_t n, int32_t stride, int32_t ubp, int32_t ibp,
+                     int32_t Pu, int32_t Pi, int32_t *out_samples, int64_t *out_block_ptr, void *stream);
+/* csr: csr.CSR.from_coo as used by Recommender.py:64 / SGDRecommender.py:265,301-302 (rowptrs, colinds),
+ * input order kept inside a row. */
+int mfsgd_hip_csr_from_coo(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users,
+                           int64_t *row_ptrs, int32_t *col_inds, void *stream);
+
+/* ---- the block grid + on-GPU scheduler + epoch kernel: replaces the scheduler actor
+ * (RayBlockScheduler.py:14-116), the worker loop (:148-181), make_subsample/update_params
+ * (SGDRecommender.py:88-121) and the per-block kernel calls.  A grid holds the ratings bucketed into
+ * Gr x Gc blocks (equal-width bins as SGDRecommender.py:191-204) as block-local runs of same-user
+ * ratings with per-item tickets, so that a workgroup can walk one block with many waves and still
+ * produce exactly the block's sequential result. */
+typedef struct mfsgd_grid mfsgd_grid;
+
+typedef struct {
+    int64_t n, n_runs, n_users, n_items;
+    int32_t Gr, Gc, ubp, ibp;
+    int32_t order;        /* 0 = reference order inside a block, 1 = user-sorted inside a block */
+    int32_t user_unique;  /* 1 if no user has two runs in one block */
+    int64_t max_block, max_col_nnz, max_row_nnz;
+} mfsgd_grid_info;
+
+/* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);
+ * order 1: rows are additionally sorted by user inside a block (throughput mode: one run per user). */
+int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
+                      int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
+int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info);
+void mfsgd_grid_destroy(mfsgd_grid *g);
+
+/* schedule 0 = fixed: equals `iters` passes over the blocks in row-major order, each block walked in
+ *               stored order (the deterministic fixed-block-order mode);
+ * schedule 1 = free-block: workgroups pull column stripes (heaviest first) and lock free row stripes
+ *               on the GPU; every block is done exactly once per epoch, conflicting blocks never overlap.
+ * order_log (nullable, int32 [iters*Gr*Gc][2], device): blocks in the order they were issued.
+ * n_workgroups / waves_per_wg: 0 = auto.  implicit in {0,1} (z required for 1). */
+int mfsgd_hip_epoch_f32(mfsgd_grid *g, int32_t k, float *P, float *Q, float *b_u, float *b_i, float b, const float *z,
+                        float alpha, float beta1, float beta2, int32_t variant, int32_t implicit,
+                        int32_t iters, int32_t schedule, uint64_t seed, int32_t n_workgroups,
+                        int32_t waves_per_wg, int32_t *order_log, void *stream);
+int mfsgd_hip_epoch_f64(mfsgd_grid *g, int32_t k, double *P, double *Q, double *b_u, double *b_i, double b, const double *z,
+                        double alpha, double beta1, double beta2, int32_t variant, int32_t implicit,
+                        int32_t iters, int32_t schedule, uint64_t seed, int32_t n_workgroups,
+                        int32_t waves_per_wg, int32_t *order_log, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -6,7 +6,7 @@
  * (recommender_amd/) never imports, links or calls anything in oracle/.
  *
  * Pinned: checked against golden vectors produced by the reference's own functions
- * imported under identity stubs (oracle/gen_golden.py -> tests/golden/*.npz), see
+ * imported under identity stubs (oracle/gen_golden.py -> tests/golden/ *.npz), see
  * tests/test_oracle_golden.py.
  *
  * Each function cites the reference lines it restates (paths under /root/reference).

@@ -53,7 +53,7 @@ def sgd(P, Q, b_u, b_i, b, y, samples, row_ptrs, col_inds, alpha, beta1, beta2,
     samples = _chk(np.ascontiguousarray(samples, dtype=np.int32), np.int32)
     rp = None if row_ptrs is None else np.ascontiguousarray(row_ptrs, dtype=np.int64)
     ci = None if col_inds is None else np.ascontiguousarray(col_inds, dtype=np.int32)
-    if implicit:
+    if implicit and z is None:
         _chk(y, P.dtype)
     rc = getattr(lib(), "orc_sgd_" + suf)(
         _p(P), _p(Q), _p(b_u), _p(b_i), ct(b), _p(y), _p(z), _p(samples), C.c_int64(samples.shape[0]),

@@ -1,0 +1,411 @@
+"""ExplicitMF: the reference's model / parameter-server class (SGDRecommender.py:28-325) with the same
+method names and semantics, driving the HIP path of libmfsgd.so.
+
+What is the same: constructor arguments and defaults (:30-44), `train(iters, multithreaded)` (:49-79)
+including the initialisation order and scales (:50-57) and the bold-driver schedules (:70-77, :318-324),
+`predict` (:82-83), `make_subsample` / `update_params` (:88-121), `generate_indpendent_samples_new`
+(:187-226), `random_renumber_samples` (:228-268), `unrandomize_samples` (:270-284), `save_all_factors`
+(:290-294), `get_ratings` / `get_rated_by_user` / `geterrors` / `increment` (:298-325), and the
+attributes P, Q, y, b_u, b_i, b, samples, test_samples, ratings, n_users, n_items, u_bins, i_bins, alpha,
+update_counter.
+
+What differs, on purpose (each is a defect of the reference):
+  * the class is a plain class, not a Ray actor; `train(..., multithreaded=True)` initialises like the
+    reference AND then runs the FPSGD epochs on the GPU (the reference leaves that to Ray workers);
+    `fit` is an alias;
+  * `update_params` merges y without raising (`if subsample.y:` on an ndarray, :96);
+  * `unrandomize_samples` really reorders the factors (inverse row permutation for P,b_u; inverse column
+    permutation for Q,y,b_i) (:280-282 only rebinds a local);
+  * `save_all_factors` writes an .npz (np.save with keywords is invalid, :292);
+  * `mse` (used at :71,:79) is broken in the reference; errors are computed by the mse2 predictor.
+"""
+import multiprocessing
+import os
+from time import perf_counter
+
+import numpy as np
+
+from . import _abi
+from .numba_methods import mse, mse2, rmse_exact, sgd, sgd2  # noqa: F401  (re-exported like `from numba_methods import *`)
+from .Recommender import Recommender
+from .SubSample import SubSample
+
+_IMPLICIT = {"none": 0, "frozen": 1, "full": 2}
+
+
+class Grid:
+    """Owner of a device block grid (mfsgd_grid_*)."""
+
+    def __init__(self, d_samples, n_users, n_items, ubp, ibp, order):
+        _abi.require_gpu()
+        h = _abi.c_vp(0)
+        _abi.check(_abi.lib().mfsgd_grid_create(_abi.ptr(d_samples), int(d_samples.shape[0]), int(d_samples.shape[1]),
+                                                int(n_users), int(n_items), int(ubp), int(ibp), int(order),
+                                                _abi.stream_ptr(), _abi.C.byref(h)))
+        self.handle = h
+        info = _abi.GridInfo()
+        _abi.check(_abi.lib().mfsgd_grid_get_info(self.handle, _abi.C.byref(info)))
+        self.info = info
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _abi.lib().mfsgd_grid_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ExplicitMF(Recommender):
+    def __init__(self,
+                 n_threads=multiprocessing.cpu_count(),
+                 n_factors=40,
+                 alpha=0.006,
+                 beta1=.05,
+                 beta2=.015,
+                 *,
+                 implicit=None,          # "none" | "frozen" | "full"; None = "full" single-thread, "frozen" FPSGD
+                 deterministic=False,    # True: reference (n_threads+1)^2 grid, fixed row-major block order
+                 dtype="float32",        # device arithmetic of the FPSGD path ("float32" | "float64")
+                 grid=None,              # (Gr, Gc) of the throughput grid; None = chosen from the shapes
+                 exact_errors=True,      # geterrors over all rows (the reference subsamples, mse2)
+                 n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
+        self.n_threads = n_threads
+        self.n_factors = n_factors
+        self.alpha = alpha
+        self.beta1 = beta1
+        self.beta2 = beta2
+        self.update_counter = 0
+        self.previous_mse = 0
+        self.timestamp = perf_counter()
+        self.implicit = implicit
+        self.deterministic = deterministic
+        self.dtype = dtype
+        self.grid_shape = grid
+        self.exact_errors = exact_errors
+        self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
+        self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
+        self.row_perm = self.col_perm = None
+        self._grid = None
+        self._dev = None             # device copies of P,Q,y,b_u,b_i while the FPSGD loop owns them
+
+    def _log(self, *a):
+        if self.verbose:
+            print(*a)
+
+    # ------------------------------------------------------------------ M1: init + training
+    def init_params(self):
+        """SGDRecommender.py:50-57: P, Q, y ~ N(0, scale=1/k) drawn in this order from the legacy global
+        RNG, zero biases, b = mean training rating."""
+        k = self.n_factors
+        self.P = np.random.normal(scale=1. / k, size=(self.n_users, k))
+        self.Q = np.random.normal(scale=1. / k, size=(self.n_items, k))
+        self.y = np.random.normal(scale=1. / k, size=(self.n_items, k))
+        self.y_owner = False
+        self.b_u = np.zeros(self.n_users)
+        self.b_i = np.zeros(self.n_items)
+        self.b = float(self._d_samples[:, 2].double().mean().item())
+
+    def train(self, iters, multithreaded=True, run=True):
+        self.init_params()
+        self._log("items,users:", self.n_users, self.n_items)
+        if not multithreaded:
+            return self._train_single(iters)
+        if run:
+            return self.run_fpsgd(iters)
+        return None
+
+    fit = train
+
+    def _train_single(self, iters):
+        """SGDRecommender.py:62-79: `iters` exact-order passes over the samples in file order, bold driver
+        (x0.5 / x1.05) on every odd epoch, test error at the end.  Factors stay on the GPU between passes."""
+        torch = _abi.torch_mod()
+        imp = self.implicit or "full"
+        rp, ci = (self._ensure_csr() if imp != "none" else (None, None))
+        td = "float64" if self.dtype == "float64" else "float32"
+        dev = [_abi.to_device(a, td) for a in (self.P, self.Q, self.b_u, self.b_i)]
+        dy = _abi.to_device(self.y, td) if imp != "none" else None
+        previous_mse = 0
+        for i in range(1, iters + 1):
+            t0 = perf_counter()
+            sgd(dev[0], dev[1], dev[2], dev[3], self.b, dy, self._d_samples, rp, ci, self.alpha, self.beta1,
+                self.beta2, implicit=imp)
+            self._log(f"SGD time: {perf_counter()-t0}")
+            if i % 2:
+                train_mse = rmse_exact(self._d_samples, rp, ci, dev[0], dev[1], dev[2], dev[3], self.b, dy)
+                if train_mse > previous_mse and previous_mse:
+                    self.alpha *= .5
+                else:
+                    self.alpha *= 1.05
+                self._log(f"Changed alpha to {self.alpha}")
+                previous_mse = train_mse - .0001
+                self._log("Iteration: %d ; train error = %.4f" % (i, train_mse))
+                self.history.append((i, train_mse, None, self.alpha))
+        test = rmse_exact(self._d_test, rp, ci, dev[0], dev[1], dev[2], dev[3], self.b, dy)
+        self._log("Test error = %.4f" % test)
+        self.P, self.Q, self.b_u, self.b_i = (t.double().cpu().numpy() for t in dev)
+        if dy is not None:
+            self.y = dy.double().cpu().numpy()
+        torch.cuda.synchronize()
+        return test
+
+    # ------------------------------------------------------------------ the GPU FPSGD path
+    def _choose_grid(self):
+        """Throughput grid: item stripes narrow enough for the Q stripe (+b_i, tickets) to sit in LDS next
+        to the scheduler words, at least ~2 stripes per workgroup; user stripes ~4x the workgroups."""
+        if self.grid_shape is not None:
+            Gr, Gc = self.grid_shape
+        else:
+            k = self.n_factors
+            esz = 8 if self.dtype == "float64" else 4
+            ibp_max = max(1, (144 * 1024) // ((k + 1) * esz + 4))
+            Gc = max(-(-self.n_items // ibp_max), min(self.n_items, 512))
+            Gr = min(self.n_users, 1024)
+        ubp = -(-self.n_users // Gr)
+        ibp = -(-self.n_items // Gc)
+        return ubp, ibp
+
+    def build_grid(self, force=False):
+        if self._grid is not None and not force:
+            return self._grid
+        if self.deterministic:
+            c = self.n_threads
+            ubp = int(self.n_users / (c + 1)) + 1      # SGDRecommender.py:191-192
+            ibp = int(self.n_items / (c + 1)) + 1
+            self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=0)
+        else:
+            ubp, ibp = self._choose_grid()
+            self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1)
+        return self._grid
+
+    def _to_dev(self):
+        td = "float64" if self.dtype == "float64" else "float32"
+        self._dev = {n: _abi.to_device(getattr(self, n), td) for n in ("P", "Q", "b_u", "b_i")}
+        self._dev["z"] = None
+        imp = self.implicit or "frozen"
+        if imp == "full":
+            raise ValueError('implicit="full" rewrites y globally on every rating and cannot run block-parallel; '
+                             'use train(iters, multithreaded=False) or implicit="frozen"/"none"')
+        if imp == "frozen":
+            torch = _abi.torch_mod()
+            rp, ci = self._ensure_csr()
+            dy = _abi.to_device(self.y, td)
+            z = torch.empty_like(self._dev["P"])
+            fn = getattr(_abi.lib(), "mfsgd_hip_implicit_z_" + ("f64" if td == "float64" else "f32"))
+            _abi.check(fn(_abi.ptr(dy), _abi.ptr(rp), _abi.ptr(ci), self.n_users, self.n_factors, 0, _abi.ptr(z),
+                          _abi.stream_ptr()))
+            self._dev["z"] = z
+        return imp
+
+    def _from_dev(self):
+        for n in ("P", "Q", "b_u", "b_i"):
+            setattr(self, n, self._dev[n].double().cpu().numpy())
+
+    def run_epochs(self, n_epochs, order_log=None):
+        """`n_epochs` FPSGD epochs on the device-resident factors (no host traffic)."""
+        d = self._dev
+        kind = "f64" if self.dtype == "float64" else "f32"
+        ct = _abi.ctype_of(kind)
+        fn = getattr(_abi.lib(), "mfsgd_hip_epoch_" + kind)
+        imp = 1 if d["z"] is not None else 0
+        _abi.check(fn(self._grid.handle, self.n_factors, _abi.ptr(d["P"]), _abi.ptr(d["Q"]), _abi.ptr(d["b_u"]),
+                      _abi.ptr(d["b_i"]), ct(self.b), _abi.ptr(d["z"]), ct(self.alpha), ct(self.beta1),
+                      ct(self.beta2), 0, imp, int(n_epochs), 0 if self.deterministic else 1,
+                      int(self.seed + self.update_counter), int(self.n_workgroups), int(self.waves_per_wg),
+                      _abi.ptr(order_log), _abi.stream_ptr()))
+
+    def device_errors(self):
+        d = self._dev
+        tr = rmse_exact(self._d_samples, None, None, d["P"], d["Q"], d["b_u"], d["b_i"], self.b, None, d["z"])
+        te = rmse_exact(self._d_test, None, None, d["P"], d["Q"], d["b_u"], d["b_i"], self.b, None, d["z"])
+        return tr, te
+
+    def run_fpsgd(self, iters):
+        """The worker loop + scheduler + parameter server of RayBlockScheduler.py:148-181 as GPU epochs.
+        Bold driver as `increment` (:315-325): after every 2 grid passes compare the train error."""
+        self.build_grid()
+        self._to_dev()
+        blocks_per_epoch = (self.n_threads + 1) ** 2
+        done = 0
+        while done < iters:
+            step = min(2, iters - done)
+            t0 = perf_counter()
+            self.run_epochs(step)
+            done += step
+            self.update_counter += step * blocks_per_epoch
+            if step == 2:
+                _abi.torch_mod().cuda.synchronize()
+                self._log(f"Full grid update took {perf_counter()-t0} s.")
+                tr, te = self.device_errors()
+                self._log("Iteration: %d ; train error = %.4f ; test error = %.4f ; lr = %.4f" % (done, tr, te, self.alpha))
+                if tr > self.previous_mse and self.previous_mse:
+                    self.alpha *= .6
+                else:
+                    self.alpha *= 1.06
+                self.previous_mse = tr - .0001
+                self.history.append((done, tr, te, self.alpha))
+        _abi.torch_mod().cuda.synchronize()
+        self._from_dev()
+        return self.history
+
+    # ------------------------------------------------------------------ P1
+    @staticmethod
+    def predict(row, col, user_vecs, item_vecs):
+        """SGDRecommender.py:82-83: plain dot of factor rows (no biases, no implicit term)."""
+        return user_vecs[row, :].dot(item_vecs[col, :].T)
+
+    def predict_rating(self, user, item):
+        """The training predictor (numba_methods.py:17) for one (user, item) in the current id space."""
+        rp, ci = self.ratings.rowptrs, self.ratings.colinds
+        rated = ci[rp[user]:rp[user + 1]]
+        ys = self.y[rated].sum(axis=0) / np.sqrt(len(rated)) if len(rated) and (self.implicit or "full") != "none" else 0.0
+        return float(self.Q[item].dot(self.P[user] + ys) + self.b_u[user] + self.b_i[item] + self.b)
+
+    # ------------------------------------------------------------------ M2
+    def _block_ranges(self, block_pos):
+        r, c = block_pos
+        return ((self.u_bins[r], min(self.u_bins[r + 1], self.n_users)),
+                (self.i_bins[c], min(self.i_bins[c + 1], self.n_items)))
+
+    def update_params(self, subsample: SubSample) -> SubSample:
+        (u0, u1), (i0, i1) = self._block_ranges(subsample.block_pos)
+        self.P[u0:u1] = subsample.P
+        self.Q[i0:i1] = subsample.Q
+        self.b_u[u0:u1] = subsample.b_u
+        self.b_i[i0:i1] = subsample.b_i
+        if subsample.y is not None and subsample.y is not False:
+            self.y = subsample.y
+        return subsample
+
+    def make_subsample(self, block_pos) -> SubSample:
+        y = self.y if self.y_owner is False else False
+        (u0, u1), (i0, i1) = self._block_ranges(block_pos)
+        return SubSample(tuple(block_pos), (u0, i0), self.P[u0:u1], self.Q[i0:i1], self.b_u[u0:u1],
+                         self.b_i[i0:i1], self.b, y, self.alpha, self.beta1, self.beta2)
+
+    # ------------------------------------------------------------------ D2 / D3 / D4
+    def random_renumber_samples(self):
+        """SGDRecommender.py:228-268: shuffle item ids, then user ids (legacy global RNG, this order), remap
+        train and test on the GPU, drop test rows whose user or item is unseen in train, rebuild the CSR."""
+        torch = _abi.torch_mod()
+        col_index = np.arange(self.n_items)
+        row_index = np.arange(self.n_users)
+        np.random.shuffle(col_index)
+        np.random.shuffle(row_index)
+        self.col_perm, self.row_perm = col_index.astype(np.int32), row_index.astype(np.int32)
+        d_rp, d_cp = _abi.to_device(self.row_perm, "int32"), _abi.to_device(self.col_perm, "int32")
+        lib = _abi.lib()
+        before = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).sort().values
+        for t in (self._d_samples, self._d_test):
+            _abi.check(lib.mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), int(t.shape[1]), _abi.ptr(d_rp),
+                                           _abi.ptr(d_cp), self.n_users, self.n_items, _abi.stream_ptr()))
+        after = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).sort().values
+        assert bool((before == after).all()), "permutation changed the per-user rating counts"
+        out = torch.empty_like(self._d_test)
+        cnt = _abi.c_i64(0)
+        _abi.check(lib.mfsgd_hip_filter_test(_abi.ptr(self._d_test), int(self._d_test.shape[0]),
+                                             int(self._d_test.shape[1]), _abi.ptr(self._d_samples),
+                                             int(self._d_samples.shape[0]), int(self._d_samples.shape[1]),
+                                             self.n_users, self.n_items, _abi.ptr(out), _abi.C.byref(cnt),
+                                             _abi.stream_ptr()))
+        self._d_test = out[:cnt.value].contiguous()
+        if self.samples is not None:
+            self.samples = self._d_samples.cpu().numpy()
+            self.test_samples = self._d_test.cpu().numpy()
+        self._build_csr()
+        self._grid = None
+
+    def generate_indpendent_samples_new(self):
+        """SGDRecommender.py:187-226: permute ids, cut users and items into n_threads+1 equal-width bins and
+        bucket the ratings, on the GPU; returns the list-of-lists of (n_b, 3) arrays the reference returns."""
+        self.random_renumber_samples()
+        torch = _abi.torch_mod()
+        c = self.n_threads
+        ubp = int(self.n_users / (c + 1)) + 1
+        ibp = int(self.n_items / (c + 1)) + 1
+        self.u_bins = [*range(0, self.n_users + ubp, ubp)]
+        self.i_bins = [*range(0, self.n_items + ibp, ibp)]
+        Pu, Pi = -(-self.n_users // ubp), -(-self.n_items // ibp)
+        n = int(self._d_samples.shape[0])
+        out = torch.empty((n, 3), dtype=torch.int32, device="cuda")
+        ptr = torch.zeros(Pu * Pi + 1, dtype=torch.int64, device="cuda")
+        _abi.check(_abi.lib().mfsgd_hip_bucket(_abi.ptr(self._d_samples), n, int(self._d_samples.shape[1]), ubp, ibp,
+                                               Pu, Pi, _abi.ptr(out), _abi.ptr(ptr), _abi.stream_ptr()))
+        self._d_blocks, self._d_block_ptr = out, ptr
+        h, p = out.cpu().numpy(), ptr.cpu().numpy()
+        groups = [[h[p[r * Pi + cc]:p[r * Pi + cc + 1]] for cc in range(Pi)] for r in range(Pu)]
+        self._log("Shape of FPSGD grid:", Pu, Pi)
+        self._log(f"Total grid samples: {n}")
+        if Pu != Pi:
+            self._log(f"warning: {Pu} user bins vs {Pi} item bins - the reference would mis-bucket here "
+                      "(SGDRecommender.py:208); every block above is still exact")
+        return groups
+
+    def get_ratings(self):
+        return self.ratings
+
+    def get_rated_by_user(self):
+        return (self.ratings.rowptrs, self.ratings.colinds)
+
+    # ------------------------------------------------------------------ M3
+    def geterrors(self, update_num):
+        self._log(f"Full grid update took {perf_counter()-self.timestamp} s.")
+        self.timestamp = perf_counter()
+        start = perf_counter()
+        rp, ci = self._ensure_csr()
+        y = None if (self.implicit == "none") else self.y
+        fn = (lambda s: rmse_exact(s, rp, ci, self.P, self.Q, self.b_u, self.b_i, self.b, y)) if self.exact_errors \
+            else (lambda s: mse2(s, rp, ci, self.P, self.Q, self.b_u, self.b_i, self.b, y if y is not None else np.zeros_like(self.Q)))
+        train_mse, test_mse = fn(self._d_samples), fn(self._d_test)
+        self._log("Iteration: %d ; train error = %.4f ; test error = %.4f ; lr = %.4f" % (update_num, train_mse, test_mse, self.alpha))
+        self._log(f"Calculated error in {perf_counter()-start} s.")
+        self.history.append((update_num, train_mse, test_mse, self.alpha))
+        return train_mse
+
+    def increment(self):
+        """SGDRecommender.py:315-325: one tick per finished block; every 2*P^2 ticks the bold driver."""
+        self.update_counter += 1
+        P2 = (self.n_threads + 1) ** 2
+        if self.update_counter % (P2 * 2) == 0:
+            train_mse = self.geterrors(self.update_counter / P2)
+            if train_mse > self.previous_mse and self.previous_mse:
+                self.alpha *= .6
+            else:
+                self.alpha *= 1.06
+            self.previous_mse = train_mse - .0001
+        return self.update_counter
+
+    # ------------------------------------------------------------------ persistence
+    def unrandomize_samples(self):
+        """Undo random_renumber_samples: ids AND factor rows go back to the original numbering."""
+        if self.row_perm is None:
+            return
+        inv_r = np.argsort(self.row_perm).astype(np.int32)      # new id -> old id
+        inv_c = np.argsort(self.col_perm).astype(np.int32)
+        d_r, d_c = _abi.to_device(inv_r, "int32"), _abi.to_device(inv_c, "int32")
+        for t in (self._d_samples, self._d_test):
+            _abi.check(_abi.lib().mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), int(t.shape[1]), _abi.ptr(d_r),
+                                                  _abi.ptr(d_c), self.n_users, self.n_items, _abi.stream_ptr()))
+        if self.samples is not None:
+            self.samples, self.test_samples = self._d_samples.cpu().numpy(), self._d_test.cpu().numpy()
+        # row `old` of the un-permuted factors is row perm[old] of the current ones
+        self.P, self.b_u = self.P[self.row_perm], self.b_u[self.row_perm]
+        self.Q, self.y, self.b_i = self.Q[self.col_perm], self.y[self.col_perm], self.b_i[self.col_perm]
+        self.row_perm = self.col_perm = None
+        self._build_csr()
+        self._grid = None
+
+    def save_all_factors(self, name):
+        os.makedirs("./factors", exist_ok=True)
+        path = f"./factors/{name},{self.n_factors}{self.alpha},{self.beta1},{self.beta2}.npz"
+        try:
+            np.savez(path, P=self.P, Q=self.Q, y=self.y, b_u=self.b_u, b_i=self.b_i, b=self.b)
+        except AttributeError:
+            print("Factors were not initialized")
+            return None
+        return path
+
+    def load_factors(self, path):
+        f = np.load(path)
+        self.P, self.Q, self.y, self.b_u, self.b_i, self.b = f["P"], f["Q"], f["y"], f["b_u"], f["b_i"], float(f["b"])

@@ -1,0 +1,787 @@
+// epoch.hip - the block grid, the on-GPU free-block scheduler and the epoch kernel.
+//
+// Replaces the scheduler actor (RayBlockScheduler.py:14-116), the worker loop (:148-181), the
+// parameter-server slicing (SGDRecommender.py:88-121) and the per-block sgd calls (:118-145).
+//
+// Data layout in HBM (all built on the device by mfsgd_grid_create):
+//   ratings sorted by block (row-major Gr x Gc, equal-width bins, SGDRecommender.py:191-204), inside a
+//   block in the reference's relative order (order 0) or additionally by user (order 1), as SoA
+//   item[n] (int32 global id), val[n] (f32), tick[n] (int32);
+//   runs = maximal stretches of consecutive ratings of one user inside a block:
+//   run_start[n_runs+1], run_user[n_runs]; blk_run_ptr[Gr*Gc+1] indexes runs by block.
+//   tick[t] = number of earlier ratings of the SAME item in the same block.
+//
+// How one block is walked (process_block): a workgroup owns block (r,c), i.e. P rows of user stripe r and
+// Q rows of item stripe c.  Waves take whole runs (one user each: P row and b_u live in registers for the
+// run).  Before a wave touches item i it waits until the item's LDS counter equals the rating's ticket and
+// bumps it afterwards, so every item sees its updates in stored order and every user's ratings are taken in
+// stored order by one wave: the result is exactly the sequential pass over the block (updates that share
+// neither user nor item commute), whatever the timing.  Q rows (and b_i) of the stripe are staged in LDS
+// when they fit (STAGE), so a hot item's chain of updates runs at LDS latency.
+//
+// How blocks are scheduled:
+//   schedule 0 (fixed): one launch per anti-diagonal of the grid; blocks on a diagonal share no row and no
+//     column, and diagonal order preserves, for every row and every column, the row-major order of its
+//     blocks - so the result equals `iters` sequential row-major passes (deterministic mode).
+//   schedule 1 (free-block): persistent workgroups pull item stripes heaviest-first from a queue (the Q
+//     stripe then stays in LDS for the whole tenure) and lock free user stripes with an agent-scope CAS;
+//     a block is done exactly once per epoch and two blocks sharing a row or a column never overlap -
+//     the FPSGD invariant of RayBlockScheduler.py:50-62 with "minimal update count" = "not yet done in this
+//     epoch".  Row hand-off between workgroups: release/acquire at agent scope around the lock word.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace mfprep {  // helpers defined in prep.hip
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename U> U *as() { return (U *)p; }
+};
+}  // namespace mfprep
+using mfprep::DevBuf;
+
+struct mfsgd_grid {
+    mfsgd_grid_info info{};
+    int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
+    float *val = nullptr;
+    int32_t *col_order = nullptr;  // item stripes, heaviest first
+    int32_t *row_lock = nullptr;   // [Gr]
+    int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
+    int32_t n_cols_nonempty = 0;
+    int device = 0;
+};
+
+namespace {
+
+struct GridView {
+    const int32_t *blk_run_ptr, *run_start, *run_user, *item, *tick;
+    const float *val;
+    const int32_t *col_order;
+    int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
+    int64_t n_users, n_items;
+};
+
+struct SchedView {
+    int32_t *row_lock, *counters, *order_log;
+    int32_t log_base;  // epoch * Gr * Gc
+    uint32_t seed;
+};
+
+inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------ grid build
+__global__ void k_keys(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t ubp, int32_t ibp, int32_t Gr,
+                       int32_t Gc, uint32_t *bkey, uint32_t *ukey, int32_t *idx, int32_t *err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t u = s[t * stride], i = s[t * stride + 1];
+    const int32_t r = u / ubp, c = i / ibp;
+    if (u < 0 || i < 0 || r >= Gr || c >= Gc) { *err = 1; bkey[t] = 0; ukey[t] = 0; idx[t] = (int32_t)t; return; }
+    bkey[t] = (uint32_t)r * (uint32_t)Gc + (uint32_t)c;
+    ukey[t] = (uint32_t)u;
+    idx[t] = (int32_t)t;
+}
+
+__global__ void k_gather_u32(const uint32_t *__restrict__ src, const int32_t *__restrict__ idx, int64_t n, uint32_t *dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[idx[t]];
+}
+
+// sorted position t <- original row idx[t]
+__global__ void k_gather_soa(const int32_t *__restrict__ s, int32_t stride, const int32_t *__restrict__ idx, int64_t n,
+                             int32_t *user, int32_t *item, float *val)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t o = idx[t];
+    user[t] = s[o * stride];
+    item[t] = s[o * stride + 1];
+    val[t] = (float)s[o * stride + 2];
+}
+
+__global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user, int64_t n, int32_t *flag)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    flag[t] = (t == 0 || bkey[t] != bkey[t - 1] || user[t] != user[t - 1]) ? 1 : 0;
+}
+
+__global__ void k_run_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ excl,
+                           const int32_t *__restrict__ user, int64_t n, int32_t n_runs, int32_t *run_start,
+                           int32_t *run_user)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) run_start[n_runs] = (int32_t)n;
+    if (t >= n || !flag[t]) return;
+    run_start[excl[t]] = (int32_t)t;
+    run_user[excl[t]] = user[t];
+}
+
+// sorted block keys -> blk_ptr (rating offsets) ; same as prep.hip's k_segment_ptr with int32 out
+__global__ void k_blk_ptr(const uint32_t *__restrict__ keys, int64_t n, int64_t nb, int32_t *ptr)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n) return;
+    const int64_t lo = t == 0 ? 0 : (int64_t)keys[t - 1] + 1;
+    const int64_t hi = t == n ? nb : (int64_t)keys[t];
+    for (int64_t b = lo; b <= hi; ++b) ptr[b] = (int32_t)t;
+}
+
+__global__ void k_blk_run_ptr(const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ excl, int64_t nb,
+                              int64_t n, int32_t n_runs, int32_t *blk_run_ptr)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    const int32_t p = blk_ptr[b];
+    blk_run_ptr[b] = p < n ? excl[p] : n_runs;
+}
+
+__global__ void k_item_keys(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ item, int64_t n,
+                            uint64_t *key, int32_t *pos)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    key[t] = ((uint64_t)bkey[t] << 32) | (uint32_t)item[t];
+    pos[t] = (int32_t)t;
+}
+
+__global__ void k_seg_start(const uint64_t *__restrict__ key, int64_t n, int32_t *start)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    start[j] = (j == 0 || key[j] != key[j - 1]) ? (int32_t)j : 0;
+}
+
+__global__ void k_ticket(const int32_t *__restrict__ segstart, const int32_t *__restrict__ pos, int64_t n, int32_t *tick)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) tick[pos[j]] = (int32_t)j - segstart[j];
+}
+
+__global__ void k_run_keys(const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_user,
+                           const uint32_t *__restrict__ bkey, int32_t n_runs, uint64_t *key)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_runs) key[j] = ((uint64_t)bkey[run_start[j]] << 32) | (uint32_t)run_user[j];
+}
+
+__global__ void k_adjacent_dup(const uint64_t *__restrict__ key, int64_t n, int32_t *dup)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j + 1 < n && key[j] == key[j + 1]) *dup = 1;
+}
+
+inline int bits_for(uint64_t maxkey)
+{
+    int b = 1;
+    while (b < 64 && (maxkey >> b)) ++b;
+    return b;
+}
+
+template <typename K, typename V>
+int sort_pairs_t(K *k_in, K *k_out, V *v_in, V *v_out, int64_t n, int end_bit, hipStream_t st)
+{
+    size_t tb = 0;
+    MF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    DevBuf tmp;
+    MF_HIP(tmp.alloc(tb));
+    MF_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    MF_HIP(hipStreamSynchronize(st));
+    return MFSGD_OK;
+}
+
+template <typename K>
+int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
+{
+    size_t tb = 0;
+    MF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, k_in, k_out, (int)n, 0, end_bit, st));
+    DevBuf tmp;
+    MF_HIP(tmp.alloc(tb));
+    MF_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, k_in, k_out, (int)n, 0, end_bit, st));
+    MF_HIP(hipStreamSynchronize(st));
+    return MFSGD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ epoch kernel
+constexpr int CTL_WORDS = 16;
+enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3 };
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
+    size_t ctl, tick, rowdone, qs, bis, total;
+};
+
+template <typename T>
+LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic)
+{
+    auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    LdsPlan<T> p{};
+    size_t o = 0;
+    p.ctl = o; o = up(o + CTL_WORDS * 4);
+    p.tick = o; o = up(o + (size_t)ibp * 4);
+    p.rowdone = o; o = up(o + (dynamic ? (size_t)Gr : 0));
+    p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
+    p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
+    p.total = o;
+    return p;
+}
+
+template <typename T, int KC, bool STAGE>
+__device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_t c_base, T *__restrict__ P,
+                                            T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b,
+                                            const T *__restrict__ z, T alpha, T beta1, T beta2, int variant, int k,
+                                            int *tick_done, T *qs, T *bis, int lane)
+{
+    const int32_t u = g.run_user[j];
+    const int32_t t0 = g.run_start[j], t1 = g.run_start[j + 1];
+    T p[KC], zz[KC], q[KC];
+    T *prow = P + (int64_t)u * k;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int f = lane + 64 * c;
+        p[c] = 0; zz[c] = 0;
+        if (f < k) {
+            p[c] = prow[f];
+            if (z) zz[c] = z[(int64_t)u * k + f];
+        }
+    }
+    // biases are rewritten by other workgroups earlier in this launch: atomic loads never become scalar loads
+    T bu = __hip_atomic_load(&b_u[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int32_t t = t0; t < t1; ++t) {
+        const int32_t ig = g.item[t];
+        const int32_t il = ig - c_base;
+        const int32_t tk = g.tick[t];
+        const T r = (T)g.val[t];
+        while (__hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tk)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        T bi;
+        T *qrow = Q + (int64_t)ig * k;
+        if (STAGE) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int f = lane + 64 * c;
+                q[c] = f < k ? qs[(size_t)il * k + f] : (T)0;
+            }
+            bi = bis[il];
+        } else {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int f = lane + 64 * c;
+                q[c] = f < k ? qrow[f] : (T)0;
+            }
+            bi = __hip_atomic_load(&b_i[ig], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        T part = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) part += q[c] * (p[c] + zz[c]);
+        const T e = r - (wave_sum(part) + bu + bi + b);
+        bu += alpha * (e - beta1 * bu);
+        bi += alpha * (e - beta1 * bi);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const T pn = p[c] + alpha * (e * q[c] - beta2 * p[c]);
+            const T pu = variant == 0 ? pn : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
+            q[c] = q[c] + alpha * (e * (pu + zz[c]) - beta2 * q[c]);
+            p[c] = pn;
+        }
+        if (STAGE) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int f = lane + 64 * c;
+                if (f < k) qs[(size_t)il * k + f] = q[c];
+            }
+            if (lane == 0) bis[il] = bi;
+        } else {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int f = lane + 64 * c;
+                if (f < k) qrow[f] = q[c];
+            }
+            if (lane == 0) __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&tick_done[il], tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int f = lane + 64 * c;
+        if (f < k) prow[f] = p[c];
+    }
+    if (lane == 0) __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// All threads of the workgroup call this; ends with a barrier after which every store of the block has been
+// issued AND completed (vmcnt drained per wave).
+template <typename T, int KC, bool STAGE>
+__device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
+                                              const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
+                                              int *tick_done, T *qs, T *bis)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int32_t bid = r * g.Gc + c;
+    const int32_t run_lo = g.blk_run_ptr[bid], run_hi = g.blk_run_ptr[bid + 1];
+    const int32_t c_base = c * g.ibp;
+    int32_t width = (int32_t)(g.n_items - c_base);
+    if (width > g.ibp) width = g.ibp;
+    for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
+    if (tid == 0) ctl[CTL_RUN] = run_lo;
+    __syncthreads();
+    if (g.user_unique) {
+        for (;;) {
+            int32_t j = 0;
+            if (lane == 0) j = atomicAdd(&ctl[CTL_RUN], 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= run_hi) break;
+            process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
+                                      qs, bis, lane);
+        }
+    } else {
+        // a user may own several runs of this block: all of them go to one wave, in stored order
+        for (int32_t j = run_lo; j < run_hi; ++j) {
+            if ((int)(mix32((uint32_t)g.run_user[j]) % (uint32_t)nw) != wave) continue;
+            process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
+                                      qs, bis, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <typename T, bool STAGE>
+__device__ __forceinline__ void stripe_load(const GridView &g, int32_t c, const T *Q, const T *b_i, int k, T *qs, T *bis)
+{
+    if (!STAGE) return;
+    const int32_t c_base = c * g.ibp;
+    int32_t width = (int32_t)(g.n_items - c_base);
+    if (width > g.ibp) width = g.ibp;
+    const T *src = Q + (int64_t)c_base * k;
+    for (int64_t i = threadIdx.x; i < (int64_t)width * k; i += blockDim.x) qs[i] = src[i];
+    for (int i = threadIdx.x; i < width; i += blockDim.x) bis[i] = b_i[c_base + i];
+    __syncthreads();
+}
+
+template <typename T, bool STAGE>
+__device__ __forceinline__ void stripe_store(const GridView &g, int32_t c, T *Q, T *b_i, int k, const T *qs, const T *bis)
+{
+    if (!STAGE) return;
+    __syncthreads();
+    const int32_t c_base = c * g.ibp;
+    int32_t width = (int32_t)(g.n_items - c_base);
+    if (width > g.ibp) width = g.ibp;
+    T *dst = Q + (int64_t)c_base * k;
+    for (int64_t i = threadIdx.x; i < (int64_t)width * k; i += blockDim.x) dst[i] = qs[i];
+    for (int i = threadIdx.x; i < width; i += blockDim.x) b_i[c_base + i] = bis[i];
+    __syncthreads();
+}
+
+// schedule 0: one launch per anti-diagonal d; workgroup w does block (r0 + w, d - r0 - w)
+template <typename T, int KC, bool STAGE>
+__global__ __launch_bounds__(1024) void k_epoch_fixed(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+                                                      T beta1, T beta2, int variant, int k, int d, int r0,
+                                                      LdsPlan<T> lp, SchedView s)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *ctl = (int *)(smem + lp.ctl);
+    int *tick_done = (int *)(smem + lp.tick);
+    T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
+    const int32_t r = r0 + (int32_t)blockIdx.x, c = d - r;
+    if (s.order_log && threadIdx.x == 0) {
+        // row-major position: the fixed schedule's log is the row-major order itself
+        s.order_log[2 * (s.log_base + r * g.Gc + c)] = r;
+        s.order_log[2 * (s.log_base + r * g.Gc + c) + 1] = c;
+    }
+    if (g.blk_run_ptr[r * g.Gc + c] == g.blk_run_ptr[r * g.Gc + c + 1]) return;
+    stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
+    process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs, bis);
+    stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
+}
+
+// schedule 1: persistent workgroups, column tenure + row locks
+template <typename T, int KC, bool STAGE>
+__global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+                                                     T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *ctl = (int *)(smem + lp.ctl);
+    int *tick_done = (int *)(smem + lp.tick);
+    unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
+    T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) {
+            const int32_t ci = __hip_atomic_fetch_add(&s.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl[CTL_COL] = ci < g.n_cols ? g.col_order[ci] : -1;
+            ctl[CTL_REMAIN] = 0;
+        }
+        __syncthreads();
+        const int32_t c = ctl[CTL_COL];
+        if (c < 0) break;
+        // rows with an empty block need no visit
+        int32_t mine = 0;
+        for (int r = tid; r < g.Gr; r += blockDim.x) {
+            const bool empty = g.blk_run_ptr[r * g.Gc + c] == g.blk_run_ptr[r * g.Gc + c + 1];
+            row_done[r] = empty ? 1 : 0;
+            mine += empty ? 0 : 1;
+        }
+        if (mine) atomicAdd(&ctl[CTL_REMAIN], mine);
+        stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
+        __syncthreads();
+        int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
+        for (;;) {
+            if (tid == 0) {
+                int32_t found = -1;
+                int32_t remain = ctl[CTL_REMAIN];
+                while (remain > 0 && found < 0) {
+                    for (int32_t rr = 0; rr < g.Gr; ++rr) {
+                        int32_t r = pos + rr;
+                        if (r >= g.Gr) r -= g.Gr;
+                        if (row_done[r]) continue;
+                        int32_t expect = 0;
+                        if (__hip_atomic_compare_exchange_strong(&s.row_lock[r], &expect, 1, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            found = r;
+                            row_done[r] = 1;
+                            pos = r + 1 == g.Gr ? 0 : r + 1;
+                            break;
+                        }
+                    }
+                    if (found < 0) __builtin_amdgcn_s_sleep(32);
+                }
+                if (found >= 0) {
+                    ctl[CTL_REMAIN] = remain - 1;
+                    // acquire: drop this CU's L1 so that the previous holder's P rows are re-read
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (s.order_log) {
+                        const int32_t slot =
+                            __hip_atomic_fetch_add(&s.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s.order_log[2 * (s.log_base + slot)] = found;
+                        s.order_log[2 * (s.log_base + slot) + 1] = c;
+                    }
+                }
+                ctl[CTL_ROW] = found;
+            }
+            __syncthreads();
+            const int32_t r = ctl[CTL_ROW];
+            if (r < 0) break;
+            process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
+                                        qs, bis);
+            if (tid == 0) {
+                // release: every wave drained its stores before the barrier that ended process_block
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&s.row_lock[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
+    }
+}
+
+template <typename T, int KC, bool STAGE>
+int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha, T beta1,
+                  T beta2, int variant, int k, int iters, int schedule, uint64_t seed, int n_wg, int waves,
+                  int32_t *order_log, hipStream_t st)
+{
+    const bool dynamic = schedule == 1;
+    const LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic);
+    if (waves <= 0) waves = 8;
+    if (waves > 16) waves = 16;
+    const int threads = waves * 64;
+    const int64_t nb = (int64_t)gv.Gr * gv.Gc;
+    if (!dynamic) {
+        auto kern = k_epoch_fixed<T, KC, STAGE>;
+        MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
+        for (int it = 0; it < iters; ++it) {
+            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed};
+            for (int d = 0; d <= gv.Gr + gv.Gc - 2; ++d) {
+                const int r0 = std::max(0, d - (gv.Gc - 1)), r1 = std::min(gv.Gr - 1, d);
+                hipLaunchKernelGGL(kern, dim3(r1 - r0 + 1), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z,
+                                   alpha, beta1, beta2, variant, k, d, r0, lp, s);
+                MF_LAUNCH_CHECK();
+            }
+        }
+        return MFSGD_OK;
+    }
+    auto kern = k_epoch_free<T, KC, STAGE>;
+    MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
+    hipDeviceProp_t prop;
+    MF_HIP(hipGetDeviceProperties(&prop, G->device));
+    if (n_wg <= 0) {
+        int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
+        per_cu = std::max(1, std::min(per_cu, std::max(1, 32 / waves)));
+        n_wg = prop.multiProcessorCount * per_cu;
+    }
+    n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
+    for (int it = 0; it < iters; ++it) {
+        MF_HIP(hipMemsetAsync(G->counters, 0, 64, st));
+        MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
+        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it)};
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2,
+                           variant, k, lp, s);
+        MF_LAUNCH_CHECK();
+    }
+    return MFSGD_OK;
+}
+
+template <typename T>
+int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha, T beta1, T beta2, int32_t variant,
+               int32_t implicit, int32_t iters, int32_t schedule, uint64_t seed, int32_t n_wg, int32_t waves,
+               int32_t *order_log, int32_t k, void *stream)
+{
+    MF_ARG(G && P && Q && b_u && b_i, "epoch: null pointer");
+    MF_ARG(k >= 1 && k <= 256, "epoch: k=%d outside [1,256]", k);
+    MF_ARG(variant == 0 || variant == 1, "epoch: variant must be 0 or 1");
+    MF_ARG(implicit == 0 || (implicit == 1 && z), "epoch: implicit must be 0, or 1 with z (2 needs the serial pass)");
+    MF_ARG(schedule == 0 || schedule == 1, "epoch: schedule must be 0 (fixed) or 1 (free-block)");
+    MF_ARG(iters >= 0, "epoch: iters < 0");
+    if (implicit == 0) z = nullptr;
+    const mfsgd_grid_info &in = G->info;
+    if (in.n == 0 || iters == 0) return MFSGD_OK;
+    GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
+                in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items};
+    const bool dynamic = schedule == 1;
+    const size_t cap = (size_t)160 * 1024;
+    const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
+    if (!stage && lds_plan<T>(in.ibp, in.Gr, k, false, dynamic).total > cap) {
+        mfsgd_set_error("epoch: item stripes of %d items (or %d row stripes) do not fit LDS; use a finer grid",
+                        in.ibp, in.Gr);
+        return MFSGD_ERR_GRID;
+    }
+    hipStream_t st = as_stream(stream);
+    const int kc = (k + 63) / 64;
+#define MF_GO(KC_)                                                                                                    \
+    return stage ? launch_epochs<T, KC_, true>(G, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, iters,   \
+                                               schedule, seed, n_wg, waves, order_log, st)                            \
+                 : launch_epochs<T, KC_, false>(G, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, iters,  \
+                                                schedule, seed, n_wg, waves, order_log, st)
+    switch (kc) {
+        case 1: MF_GO(1);
+        case 2: MF_GO(2);
+        case 3: MF_GO(3);
+        default: MF_GO(4);
+    }
+#undef MF_GO
+}
+
+}  // namespace
+
+extern "C" {
+
+void mfsgd_grid_destroy(mfsgd_grid *g)
+{
+    if (!g) return;
+    void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
+                    g->counters};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info)
+{
+    MF_ARG(g && info, "grid_get_info: null pointer");
+    *info = g->info;
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
+                      int32_t ibp, int32_t order, void *stream, mfsgd_grid **out)
+{
+    MF_ARG(out, "grid_create: null out");
+    *out = nullptr;
+    MF_ARG(n >= 0 && n < ((int64_t)1 << 31) - 1, "grid_create: n=%lld must fit int32", (long long)n);
+    MF_ARG(stride >= 3 && n_users > 0 && n_items > 0 && ubp > 0 && ibp > 0, "grid_create: bad shape argument");
+    MF_ARG(order == 0 || order == 1, "grid_create: order must be 0 or 1");
+    MF_ARG(n == 0 || samples, "grid_create: null samples");
+    const int64_t Gr = (n_users + ubp - 1) / ubp, Gc = (n_items + ibp - 1) / ibp, nb = Gr * Gc;
+    MF_ARG(nb < ((int64_t)1 << 30), "grid_create: %lld x %lld blocks is too many", (long long)Gr, (long long)Gc);
+    hipStream_t st = as_stream(stream);
+    mfsgd_grid *G = new mfsgd_grid();
+    struct Guard { mfsgd_grid *g; ~Guard() { if (g) mfsgd_grid_destroy(g); } } guard{G};
+    MF_HIP(hipGetDevice(&G->device));
+    G->info.n = n; G->info.n_users = n_users; G->info.n_items = n_items;
+    G->info.Gr = (int32_t)Gr; G->info.Gc = (int32_t)Gc; G->info.ubp = ubp; G->info.ibp = ibp; G->info.order = order;
+    G->info.user_unique = 1;
+    auto dalloc = [&](auto **p, size_t count) { return hipMalloc((void **)p, (count ? count : 1) * sizeof(**p)); };
+    MF_HIP(dalloc(&G->blk_run_ptr, (size_t)nb + 1));
+    MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
+    MF_HIP(dalloc(&G->col_order, (size_t)Gc));
+    MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
+    MF_HIP(dalloc(&G->counters, 16));
+    std::vector<int32_t> h_blk((size_t)nb + 1, 0);
+    if (n == 0) {
+        MF_HIP(hipMemsetAsync(G->blk_run_ptr, 0, sizeof(int32_t) * (size_t)(nb + 1), st));
+        MF_HIP(dalloc(&G->run_start, 1)); MF_HIP(dalloc(&G->run_user, 1));
+        MF_HIP(hipMemsetAsync(G->run_start, 0, 4, st));
+        MF_HIP(hipStreamSynchronize(st));
+        guard.g = nullptr; *out = G;
+        return MFSGD_OK;
+    }
+    // 1. keys and the stable sort(s)
+    DevBuf bk0, bk1, uk0, uk1, ix0, ix1, err;
+    MF_HIP(bk0.alloc((size_t)n * 4)); MF_HIP(bk1.alloc((size_t)n * 4));
+    MF_HIP(uk0.alloc((size_t)n * 4)); MF_HIP(uk1.alloc((size_t)n * 4));
+    MF_HIP(ix0.alloc((size_t)n * 4)); MF_HIP(ix1.alloc((size_t)n * 4));
+    MF_HIP(err.alloc(4));
+    MF_HIP(hipMemsetAsync(err.p, 0, 4, st));
+    hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, ubp, ibp, (int32_t)Gr, (int32_t)Gc,
+                       bk0.as<uint32_t>(), uk0.as<uint32_t>(), ix0.as<int32_t>(), err.as<int32_t>());
+    MF_LAUNCH_CHECK();
+    int32_t herr = 0;
+    MF_HIP(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (herr) { mfsgd_set_error("grid_create: a sample lies outside [0,%lld) x [0,%lld)", (long long)n_users, (long long)n_items); return MFSGD_ERR_GRID; }
+    int rc;
+    int32_t *idx_sorted;
+    if (order == 1) {
+        // LSD: stable by user first, then stable by block
+        rc = sort_pairs_t(uk0.as<uint32_t>(), uk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
+                          bits_for((uint64_t)n_users), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_u32, dim3(nblk(n)), dim3(256), 0, st, bk0.as<uint32_t>(), ix1.as<int32_t>(), n,
+                           bk1.as<uint32_t>());
+        MF_LAUNCH_CHECK();
+        rc = sort_pairs_t(bk1.as<uint32_t>(), bk0.as<uint32_t>(), ix1.as<int32_t>(), ix0.as<int32_t>(), n,
+                          bits_for((uint64_t)nb), st);
+        if (rc) return rc;
+        idx_sorted = ix0.as<int32_t>();   // sorted block keys now in bk0
+    } else {
+        rc = sort_pairs_t(bk0.as<uint32_t>(), bk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
+                          bits_for((uint64_t)nb), st);
+        if (rc) return rc;
+        MF_HIP(hipMemcpyAsync(bk0.p, bk1.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        idx_sorted = ix1.as<int32_t>();
+    }
+    uint32_t *bkey = bk0.as<uint32_t>();  // sorted
+    // 2. SoA payload in sorted order
+    DevBuf user;
+    MF_HIP(user.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(k_gather_soa, dim3(nblk(n)), dim3(256), 0, st, samples, stride, idx_sorted, n,
+                       user.as<int32_t>(), G->item, G->val);
+    MF_LAUNCH_CHECK();
+    // 3. runs
+    DevBuf flag, excl, tmp;
+    MF_HIP(flag.alloc((size_t)n * 4)); MF_HIP(excl.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(k_run_flags, dim3(nblk(n)), dim3(256), 0, st, bkey, user.as<int32_t>(), n, flag.as<int32_t>());
+    MF_LAUNCH_CHECK();
+    {
+        size_t tb = 0;
+        MF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag.as<int32_t>(), excl.as<int32_t>(), (int)n, st));
+        MF_HIP(tmp.alloc(tb));
+        MF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, flag.as<int32_t>(), excl.as<int32_t>(), (int)n, st));
+    }
+    int32_t last_excl = 0, last_flag = 0;
+    MF_HIP(hipMemcpyAsync(&last_excl, excl.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(&last_flag, flag.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    const int32_t n_runs = last_excl + last_flag;
+    G->info.n_runs = n_runs;
+    MF_HIP(dalloc(&G->run_start, (size_t)n_runs + 1)); MF_HIP(dalloc(&G->run_user, (size_t)n_runs));
+    hipLaunchKernelGGL(k_run_fill, dim3(nblk(n)), dim3(256), 0, st, flag.as<int32_t>(), excl.as<int32_t>(),
+                       user.as<int32_t>(), n, n_runs, G->run_start, G->run_user);
+    MF_LAUNCH_CHECK();
+    DevBuf blk_ptr;
+    MF_HIP(blk_ptr.alloc(((size_t)nb + 1) * 4));
+    hipLaunchKernelGGL(k_blk_ptr, dim3(nblk(n + 1)), dim3(256), 0, st, bkey, n, nb, blk_ptr.as<int32_t>());
+    MF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_blk_run_ptr, dim3(nblk(nb + 1)), dim3(256), 0, st, blk_ptr.as<int32_t>(), excl.as<int32_t>(),
+                       nb, n, n_runs, G->blk_run_ptr);
+    MF_LAUNCH_CHECK();
+    MF_HIP(hipMemcpyAsync(h_blk.data(), blk_ptr.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
+    // 4. tickets: rank of a rating among the ratings of its (block, item), in stored order
+    {
+        DevBuf k0, k1, p0, p1, seg;
+        MF_HIP(k0.alloc((size_t)n * 8)); MF_HIP(k1.alloc((size_t)n * 8));
+        MF_HIP(p0.alloc((size_t)n * 4)); MF_HIP(p1.alloc((size_t)n * 4)); MF_HIP(seg.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(k_item_keys, dim3(nblk(n)), dim3(256), 0, st, bkey, G->item, n, k0.as<uint64_t>(),
+                           p0.as<int32_t>());
+        MF_LAUNCH_CHECK();
+        rc = sort_pairs_t(k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), p1.as<int32_t>(), n,
+                          32 + bits_for((uint64_t)nb), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_seg_start, dim3(nblk(n)), dim3(256), 0, st, k1.as<uint64_t>(), n, seg.as<int32_t>());
+        MF_LAUNCH_CHECK();
+        size_t tb = 0;
+        DevBuf tmp2;
+        MF_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, seg.as<int32_t>(), p0.as<int32_t>(), hipcub::Max(), (int)n, st));
+        MF_HIP(tmp2.alloc(tb));
+        MF_HIP(hipcub::DeviceScan::InclusiveScan(tmp2.p, tb, seg.as<int32_t>(), p0.as<int32_t>(), hipcub::Max(), (int)n, st));
+        hipLaunchKernelGGL(k_ticket, dim3(nblk(n)), dim3(256), 0, st, p0.as<int32_t>(), p1.as<int32_t>(), n, G->tick);
+        MF_LAUNCH_CHECK();
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    // 5. does any user own two runs of one block?  (never for order 1)
+    if (order == 0 && n_runs > 1) {
+        DevBuf rk0, rk1, dup;
+        MF_HIP(rk0.alloc((size_t)n_runs * 8)); MF_HIP(rk1.alloc((size_t)n_runs * 8)); MF_HIP(dup.alloc(4));
+        MF_HIP(hipMemsetAsync(dup.p, 0, 4, st));
+        hipLaunchKernelGGL(k_run_keys, dim3(nblk(n_runs)), dim3(256), 0, st, G->run_start, G->run_user, bkey, n_runs,
+                           rk0.as<uint64_t>());
+        MF_LAUNCH_CHECK();
+        rc = sort_keys_t(rk0.as<uint64_t>(), rk1.as<uint64_t>(), n_runs, 32 + bits_for((uint64_t)nb), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_adjacent_dup, dim3(nblk(n_runs)), dim3(256), 0, st, rk1.as<uint64_t>(), (int64_t)n_runs,
+                           dup.as<int32_t>());
+        MF_LAUNCH_CHECK();
+        int32_t hd = 0;
+        MF_HIP(hipMemcpyAsync(&hd, dup.p, 4, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        G->info.user_unique = hd ? 0 : 1;
+    }
+    MF_HIP(hipStreamSynchronize(st));
+    // 6. stripe weights (host, Gr*Gc words): heaviest item stripe first
+    std::vector<int64_t> col_nnz((size_t)Gc, 0), row_nnz((size_t)Gr, 0);
+    int64_t max_block = 0;
+    for (int64_t r = 0; r < Gr; ++r)
+        for (int64_t c = 0; c < Gc; ++c) {
+            const int64_t m = (int64_t)h_blk[r * Gc + c + 1] - h_blk[r * Gc + c];
+            col_nnz[c] += m; row_nnz[r] += m; max_block = std::max(max_block, m);
+        }
+    std::vector<int32_t> ord((size_t)Gc);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b2) { return col_nnz[a] > col_nnz[b2]; });
+    int32_t ne = 0;
+    while (ne < Gc && col_nnz[ord[ne]] > 0) ++ne;
+    G->n_cols_nonempty = ne;
+    G->info.max_block = max_block;
+    G->info.max_col_nnz = *std::max_element(col_nnz.begin(), col_nnz.end());
+    G->info.max_row_nnz = *std::max_element(row_nnz.begin(), row_nnz.end());
+    MF_HIP(hipMemcpyAsync(G->col_order, ord.data(), sizeof(int32_t) * (size_t)Gc, hipMemcpyHostToDevice, st));
+    MF_HIP(hipStreamSynchronize(st));
+    guard.g = nullptr;
+    *out = G;
+    return MFSGD_OK;
+}
+
+int mfsgd_hip_epoch_f32(mfsgd_grid *g, int32_t k, float *P, float *Q, float *b_u, float *b_i, float b, const float *z,
+                        float alpha, float beta1, float beta2, int32_t variant, int32_t implicit, int32_t iters,
+                        int32_t schedule, uint64_t seed, int32_t n_workgroups, int32_t waves_per_wg,
+                        int32_t *order_log, void *stream)
+{
+    return epoch_impl<float>(g, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, implicit, iters, schedule, seed,
+                             n_workgroups, waves_per_wg, order_log, k, stream);
+}
+
+int mfsgd_hip_epoch_f64(mfsgd_grid *g, int32_t k, double *P, double *Q, double *b_u, double *b_i, double b,
+                        const double *z, double alpha, double beta1, double beta2, int32_t variant, int32_t implicit,
+                        int32_t iters, int32_t schedule, uint64_t seed, int32_t n_workgroups, int32_t waves_per_wg,
+                        int32_t *order_log, void *stream)
+{
+    return epoch_impl<double>(g, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, implicit, iters, schedule, seed,
+                              n_workgroups, waves_per_wg, order_log, k, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libmfsgd.so) against the golden vectors captured
+from the reference and against the CPU oracle.  Run on an MI355X with `-m gpu`.
+
+Tolerances: integer work (remap, filter, bucketing, CSR, scheduler coverage) is bit-exact; float64
+kernels match the reference to 1e-9 relative (different summation tree only); float32 kernels to
+north_star's 1e-4 relative; RMSE to 0.002 (north_star) - in practice far tighter, asserted at 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+HP = (0.006, 0.05, 0.015)
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def relerr(a, ref):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import recommender_amd
+    from recommender_amd import _abi
+    _abi.require_gpu()
+    return recommender_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+# ------------------------------------------------------------------ A1 / A2 / A3 kernels
+@pytest.mark.parametrize("k", [4, 32, 128])
+@pytest.mark.parametrize("tag,fn,implicit,skey", [
+    ("a1", "sgd", "full", "samples"), ("a3", "sgd2", "full", "samples"), ("a1s", "sgd", "full", "shuffled"),
+    ("none", "sgd", "none", "samples"), ("frozen", "sgd", "frozen", "samples")])
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-9), (np.float32, 1e-4)])
+def test_sgd_kernels_vs_golden(ra, k, tag, fn, implicit, skey, dt, tol):
+    g = load(f"kernels_k{k}.npz")
+    P, Q, y, bu, bi = (g[n].astype(dt) for n in ("P", "Q", "y", "b_u", "b_i"))
+    ret = getattr(ra, fn)(P, Q, bu, bi, float(g["b"]), y, g[skey], g["row_ptrs"], g["col_inds"], *HP, implicit=implicit)
+    assert ret[0] is P and ret[1] is Q and ret[2] is y and ret[3] is bu and ret[4] is bi   # in place AND returned
+    for name, arr in (("P", P), ("Q", Q), ("b_u", bu), ("b_i", bi)):
+        assert relerr(arr, g[f"{tag}_{name}"]) <= tol, name
+    if implicit == "full":
+        assert relerr(y, g[f"{tag}_y"]) <= tol
+    else:
+        np.testing.assert_array_equal(y, g["y"].astype(dt))
+
+
+def test_sgd_torch_tensors_zero_copy(ra):
+    import torch
+    g = load("kernels_k32.npz")
+    dev = [torch.from_numpy(g[n]).cuda() for n in ("P", "Q", "b_u", "b_i")]
+    y = torch.from_numpy(g["y"]).cuda()
+    ptrs = [t.data_ptr() for t in dev]
+    ra.sgd(dev[0], dev[1], dev[2], dev[3], float(g["b"]), y, torch.from_numpy(g["samples"]).cuda(),
+           torch.from_numpy(g["row_ptrs"]).cuda(), torch.from_numpy(g["col_inds"]).cuda(), *HP)
+    assert [t.data_ptr() for t in dev] == ptrs
+    assert relerr(dev[0].cpu().numpy(), g["a1_P"]) <= 1e-9 and relerr(y.cpu().numpy(), g["a1_y"]) <= 1e-9
+
+
+def test_block_sgd_g3(ra):
+    g = load("pipeline_a.npz")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    ub, ib = g["u_bins"], g["i_bins"]
+    u0, i0 = (int(v) for v in g["g3_off"])
+    u1, i1 = min(int(ub[2]), U), min(int(ib[3]), I)
+    blocks, sizes = g["blocks_concat"], g["block_sizes"]
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    P, Q, y = g["m1_P"][u0:u1].copy(), g["m1_Q"][i0:i1].copy(), g["m1_y"].copy()
+    bu, bi = np.zeros(u1 - u0), np.zeros(i1 - i0)
+    ra.block_sgd((u0, i0), P, Q, bu, bi, float(g["m1_b"]), y, blocks[ptr[6]:ptr[7]], g["d4_rowptrs"], g["d4_colinds"], *HP)
+    for name, arr in (("P", P), ("Q", Q), ("b_u", bu), ("b_i", bi), ("y", y)):
+        assert relerr(arr, g[f"g3_{name}"]) <= 1e-9, name
+
+
+def test_sgd_rejects_bad_arguments(ra):
+    g = load("kernels_k4.npz")
+    P, Q, y, bu, bi = (g[n].copy() for n in ("P", "Q", "y", "b_u", "b_i"))
+    with pytest.raises(ValueError):
+        ra.sgd(P, Q, bu, bi, 0.0, y, g["samples"][:, :2], g["row_ptrs"], g["col_inds"], *HP)
+    with pytest.raises(ValueError):
+        ra.sgd(P, Q[:, :2].copy(), bu, bi, 0.0, y, g["samples"], g["row_ptrs"], g["col_inds"], *HP)
+    # empty input is a no-op
+    ra.sgd(P, Q, bu, bi, 0.0, y, g["samples"][:0], g["row_ptrs"], g["col_inds"], *HP)
+    np.testing.assert_array_equal(P, g["P"])
+
+
+# ------------------------------------------------------------------ A4 RMSE
+@pytest.mark.parametrize("k", [4, 32, 128])
+def test_rmse_vs_golden(ra, k):
+    g = load(f"kernels_k{k}.npz")
+    args = (g["row_ptrs"], g["col_inds"], g["P"], g["Q"], g["b_u"], g["b_i"], float(g["b"]), g["y"])
+    assert abs(ra.mse2(g["samples"], *args, exact=True) - float(g["rmse_exact_init"])) < 1e-10
+    np.random.seed(77)
+    assert abs(ra.mse2(g["samples"], *args) - float(g["mse2_seed77"])) < 1e-10     # same subsample as the reference
+    a1 = (g["row_ptrs"], g["col_inds"], g["a1_P"], g["a1_Q"], g["a1_b_u"], g["a1_b_i"], float(g["b"]), g["a1_y"])
+    assert abs(ra.mse2(g["samples"], *a1, exact=True) - float(g["a1_rmse_exact"])) < 1e-10
+    f32 = tuple(a.astype(np.float32) if isinstance(a, np.ndarray) and a.dtype == np.float64 else a for a in args)
+    assert abs(ra.mse2(g["samples"], *f32, exact=True) - float(g["rmse_exact_init"])) < 1e-5
+
+
+# ------------------------------------------------------------------ D1-D4 through ExplicitMF
+@pytest.mark.parametrize("tag", ["a", "b", "shuf", "ragged"])
+def test_prep_bit_exact_through_explicitmf(ra, tag):
+    g = load(f"pipeline_{tag}.npz")
+    m = ra.ExplicitMF(n_threads=int(g["n_threads"]), n_factors=int(g["k"]), verbose=False)
+    np.random.seed(int(g["seed"]))
+    m.load_samples_from_array(g["raw"], "all")
+    np.testing.assert_array_equal(m.samples, g["d1_samples"])
+    np.testing.assert_array_equal(m.test_samples, g["d1_test"])
+    np.testing.assert_array_equal(m.ratings.rowptrs, g["d1_rowptrs"])
+    np.testing.assert_array_equal(m.ratings.colinds, g["d1_colinds"])
+    groups = m.generate_indpendent_samples_new()
+    np.testing.assert_array_equal(m.row_perm, g["row_perm"])
+    np.testing.assert_array_equal(m.col_perm, g["col_perm"])
+    np.testing.assert_array_equal(m.samples, g["d2_samples"])
+    np.testing.assert_array_equal(m.test_samples, g["d2_test"])
+    np.testing.assert_array_equal(m.u_bins, g["u_bins"])
+    np.testing.assert_array_equal(m.i_bins, g["i_bins"])
+    rp, ci = m.get_rated_by_user()
+    np.testing.assert_array_equal(rp, g["d4_rowptrs"])
+    np.testing.assert_array_equal(ci, g["d4_colinds"])
+    assert [len(row) for row in groups] == [int(g["grid_shape"][1])] * int(g["grid_shape"][0])
+    flat = [b for row in groups for b in row]
+    np.testing.assert_array_equal(np.array([len(b) for b in flat]), g["block_sizes"])
+    np.testing.assert_array_equal(np.concatenate(flat), g["blocks_concat"])
+    assert sum(len(b) for b in flat) == len(m.samples)
+
+
+def test_prep_edge_cases(ra):
+    import torch
+    from recommender_amd import _abi
+    lib = _abi.lib()
+    # a sample outside the grid is an error, not a fault
+    s = torch.tensor([[0, 0, 1], [5, 9, 2]], dtype=torch.int32, device="cuda")
+    out = torch.empty((2, 3), dtype=torch.int32, device="cuda")
+    ptr = torch.zeros(5, dtype=torch.int64, device="cuda")
+    rc = lib.mfsgd_hip_bucket(_abi.ptr(s), 2, 3, 3, 3, 2, 2, _abi.ptr(out), _abi.ptr(ptr), None)
+    assert rc != 0 and b"outside" in lib.mfsgd_last_error()
+    # empty input
+    rc = lib.mfsgd_hip_bucket(None, 0, 3, 3, 3, 2, 2, None, _abi.ptr(ptr), None)
+    assert rc == 0 and ptr.cpu().tolist() == [0] * 5
+    # a block that is empty, a single-row block, stride 4
+    s = torch.tensor([[0, 0, 1, 7], [1, 5, 2, 7], [0, 1, 3, 7]], dtype=torch.int32, device="cuda")
+    out = torch.empty((3, 3), dtype=torch.int32, device="cuda")
+    assert lib.mfsgd_hip_bucket(_abi.ptr(s), 3, 4, 1, 3, 2, 2, _abi.ptr(out), _abi.ptr(ptr), None) == 0
+    assert ptr.cpu().tolist() == [0, 2, 2, 2, 3]
+    assert out.cpu().tolist() == [[0, 0, 1], [0, 1, 3], [1, 5, 2]]
+
+
+# ------------------------------------------------------------------ G8: fixed block order, whole model
+@pytest.mark.parametrize("tag", ["a", "b", "shuf"])
+@pytest.mark.parametrize("mode", ["none", "frozen"])
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
+def test_deterministic_mode_matches_reference(ra, tag, mode, dtype, tol):
+    """ExplicitMF in deterministic mode = the reference's blocks in fixed row-major order (G8)."""
+    g = load(f"pipeline_{tag}.npz")
+    m = ra.ExplicitMF(n_threads=int(g["n_threads"]), n_factors=int(g["k"]), implicit=mode, deterministic=True,
+                      dtype=dtype, verbose=False)
+    np.random.seed(int(g["seed"]))
+    m.load_samples_from_array(g["raw"], "all")
+    m.generate_indpendent_samples_new()
+    m.train(1, multithreaded=True, run=False)          # initialise exactly as the reference's train(1, True)
+    np.testing.assert_array_equal(m.P, g["m1_P"])
+    np.testing.assert_array_equal(m.Q, g["m1_Q"])
+    np.testing.assert_array_equal(m.y, g["m1_y"])
+    assert m.b == float(g["m1_b"])
+    m.build_grid()
+    m._to_dev()
+    m.run_epochs(int(g["iters"]))                      # constant alpha, like the golden run
+    tr, te = m.device_errors()
+    m._from_dev()
+    for name in ("P", "Q", "b_u", "b_i"):
+        assert relerr(getattr(m, name), g[f"g8_{mode}_{name}"]) <= tol, name
+    assert abs(tr - float(g[f"g8_{mode}_train_rmse"])) < 1e-4
+    assert abs(te - float(g[f"g8_{mode}_test_rmse"])) < 1e-4
+
+
+# ------------------------------------------------------------------ free-block schedule == some serial order
+def _synthetic(rng, U, I, n):
+    u = (U * rng.random(n) ** 1.7).astype(np.int64)
+    i = (I * rng.random(n) ** 2.2).astype(np.int64)
+    key = np.unique(u * I + i)
+    u, i = key // I, key % I
+    r = rng.integers(1, 6, size=len(key))
+    return np.column_stack([u, i, r]).astype(np.int32)
+
+
+@pytest.mark.parametrize("k,U,I,n,grid,waves", [
+    (32, 500, 300, 30000, (8, 6), 4),
+    (128, 3000, 900, 200000, (64, 16), 8),
+    (64, 2000, 5000, 150000, (32, 32), 16),
+    (200, 700, 400, 40000, (16, 8), 8),
+])
+@pytest.mark.parametrize("mode", ["none", "frozen"])
+def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode):
+    """The on-GPU scheduler may issue blocks in any conflict-free order; its log, replayed block by block
+    through the CPU oracle, must reproduce the GPU factors (fp32 tolerance), every block exactly once/epoch."""
+    import torch
+    from recommender_amd import _abi
+    from recommender_amd.SGDRecommender import Grid
+    rng = np.random.default_rng(k + n)
+    s = _synthetic(rng, U, I, n)
+    Gr, Gc = grid
+    ubp, ibp = -(-U // Gr), -(-I // Gc)
+    Gr, Gc = -(-U // ubp), -(-I // ibp)
+    d_s = torch.from_numpy(s).cuda()
+    gr = Grid(d_s, U, I, ubp, ibp, order=1)
+    assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
+    P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
+    Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
+    y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
+    bu, bi = np.zeros(U, np.float32), np.zeros(I, np.float32)
+    b = float(s[:, 2].mean())
+    rp, ci = orc.csr_from_coo(s, U)
+    z = orc.implicit_z(y, rp, ci, U) if mode == "frozen" else None
+    dP, dQ, dbu, dbi = (torch.from_numpy(a.copy()).cuda() for a in (P, Q, bu, bi))
+    dz = torch.from_numpy(z).cuda() if z is not None else None
+    iters = 2
+    log = torch.full((iters * Gr * Gc, 2), -1, dtype=torch.int32, device="cuda")
+    _abi.check(_abi.lib().mfsgd_hip_epoch_f32(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
+                                              b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, 1, 1234, 0,
+                                              waves, _abi.ptr(log), None))
+    torch.cuda.synchronize()
+    log = log.cpu().numpy().reshape(iters, Gr * Gc, 2)
+    # oracle replay: the same blocks (user-sorted inside a block, as order=1 stores them) in logged order
+    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
+    order = np.lexsort((s[:, 0], key))          # stable: block, then user, then input order
+    ss, ks = s[order], key[order]
+    ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
+    nonempty = {(b_ // Gc, b_ % Gc) for b_ in range(Gr * Gc) if ptr[b_ + 1] > ptr[b_]}
+    for e in range(iters):
+        issued = [tuple(x) for x in log[e] if x[0] >= 0]
+        assert len(issued) == len(set(issued)) and set(issued) == nonempty
+        for r, c in issued:
+            blk = ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]]
+            orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z)
+    for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
+        assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= 1e-4, name
+
+
+def test_throughput_mode_rmse_close_to_deterministic(ra):
+    """north_star: throughput mode's held-out RMSE within 0.002 of the fixed-order run."""
+    g = load("real_ml_small_20k.npz")
+    out = {}
+    for det in (True, False):
+        m = ra.ExplicitMF(n_threads=int(g["n_threads"]), n_factors=int(g["k"]), implicit="none", deterministic=det,
+                          grid=None if det else (16, 16), verbose=False)
+        np.random.seed(int(g["seed"]))
+        m.load_samples_from_array(g["raw"], "all")
+        m.generate_indpendent_samples_new()
+        m.train(1, multithreaded=True, run=False)
+        m.build_grid(); m._to_dev(); m.run_epochs(int(g["iters"]))
+        out[det] = m.device_errors()
+    assert abs(out[True][0] - float(g["train_rmse"])) < 1e-4 and abs(out[True][1] - float(g["test_rmse"])) < 1e-4
+    assert abs(out[False][1] - float(g["test_rmse"])) < 0.002
+
+
+def test_train_api_end_to_end(ra):
+    g = load("pipeline_a.npz")
+    m = ra.ExplicitMF(n_threads=3, n_factors=8, implicit="frozen", verbose=False)
+    np.random.seed(3)
+    m.load_samples_from_array(g["raw"], "all")
+    m.generate_indpendent_samples_new()
+    hist = m.fit(6)
+    assert len(hist) == 3 and hist[-1][1] < hist[0][1] + 1e-9        # train error does not rise over the run
+    assert m.P.shape == (m.n_users, 8) and m.P.dtype == np.float64
+    pr = ra.ExplicitMF.predict(np.array([0, 1]), np.array([2]), m.P, m.Q)
+    assert pr.shape == (2, 1)
+    # undo the permutation: the factor rows follow their users back to the original numbering
+    u_new, i_new = int(m.samples[0, 0]), int(m.samples[0, 1])
+    before = m.predict_rating(u_new, i_new)
+    m.unrandomize_samples()
+    u_old, i_old = int(m.samples[0, 0]), int(m.samples[0, 1])
+    assert abs(m.predict_rating(u_old, i_old) - before) < 1e-12
+    # single-thread path (exact order, SVD++ y updates) runs and reports a test error
+    m2 = ra.ExplicitMF(n_threads=3, n_factors=8, dtype="float64", verbose=False)
+    np.random.seed(3)
+    m2.load_samples_from_array(g["raw"], "all")
+    assert 0.5 < m2.train(3, multithreaded=False) < 3.0
+
+
+def test_consumer_loop_matches_golden_full_mode(ra):
+    """Reference-style driver: host BlockScheduler + make_subsample + block_sgd + update_params, y merged.
+    With the deterministic tie-break and one consumer the block order is fixed; compare RMSE with G8 'full'
+    run in the S2 order through the oracle."""
+    from oracle import oracle as orc
+    g = load("pipeline_a.npz")
+    m = ra.ExplicitMF(n_threads=3, n_factors=8, verbose=False)
+    np.random.seed(11)
+    m.load_samples_from_array(g["raw"], "all")
+    groups = m.generate_indpendent_samples_new()
+    m.train(1, multithreaded=True, run=False)
+    rp, ci = m.get_rated_by_user()
+    P, Q, y, bu, bi = m.P.copy(), m.Q.copy(), m.y.copy(), m.b_u.copy(), m.b_i.copy()
+    sched = ra.BlockScheduler(4, 2, deterministic=True)
+    m.exact_errors = True
+    n = ra.consumer(sched, m, groups, rp, ci)
+    assert n == 32 and sched.check_completion()
+    s2 = orc.Scheduler(4, 2, deterministic=True)
+    blk = s2.get_next()
+    alpha = 0.006
+    ticks = 0
+    while blk is not None:
+        r, c = blk
+        u0, u1 = m.u_bins[r], min(m.u_bins[r + 1], m.n_users)
+        i0, i1 = m.i_bins[c], min(m.i_bins[c + 1], m.n_items)
+        orc.sgd(P[u0:u1], Q[i0:i1], bu[u0:u1], bi[i0:i1], m.b, y, groups[r][c], rp, ci, alpha, 0.05, 0.015,
+                idx_offset=(u0, i0))
+        ticks += 1
+        if ticks % 32 == 0:
+            alpha *= 1.06
+        blk = s2.get_next(completed=blk)
+    for name, ref in (("P", P), ("Q", Q), ("y", y), ("b_u", bu), ("b_i", bi)):
+        assert relerr(getattr(m, name), ref) <= 1e-9, name
+    assert m.alpha == pytest.approx(0.006 * 1.06)
