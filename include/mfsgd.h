@@ -118,6 +118,13 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
                       int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info);
 void mfsgd_grid_destroy(mfsgd_grid *g);
+/* Copies the grid's arrays into caller buffers (any may be NULL): blk_run_ptr[Gr*Gc+1], run_start[n_runs+1],
+ * run_user[n_runs], item[n], val[n], tick[n].  For checking the bucketing bit for bit. */
+int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_start, int32_t *run_user,
+                      int32_t *item, float *val, int32_t *tick, void *stream);
+/* Synchronises and reports whether an epoch kernel ran out of patience on a wait (every spin in the
+ * kernels is bounded); clears the flag. */
+int mfsgd_grid_status(mfsgd_grid *g, void *stream);
 
 /* schedule 0 = fixed: equals `iters` passes over the blocks in row-major order, each block walked in
  *               stored order (the deterministic fixed-block-order mode);

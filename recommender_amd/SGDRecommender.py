@@ -47,6 +47,29 @@ class Grid:
         _abi.check(_abi.lib().mfsgd_grid_get_info(self.handle, _abi.C.byref(info)))
         self.info = info
 
+    def status(self):
+        """Synchronise and raise if an epoch kernel gave up on a bounded wait."""
+        _abi.check(_abi.lib().mfsgd_grid_status(self.handle, _abi.stream_ptr()))
+
+    def export(self):
+        """Host copies of the grid arrays (tests: bucketing must be bit-exact)."""
+        torch = _abi.torch_mod()
+        i = self.info
+        nb, n, nr = i.Gr * i.Gc, int(i.n), int(i.n_runs)
+        t = {"blk_run_ptr": torch.zeros(nb + 1, dtype=torch.int32, device="cuda"),
+             "run_start": torch.zeros(nr + 1, dtype=torch.int32, device="cuda"),
+             "run_user": torch.zeros(max(nr, 1), dtype=torch.int32, device="cuda"),
+             "item": torch.zeros(max(n, 1), dtype=torch.int32, device="cuda"),
+             "val": torch.zeros(max(n, 1), dtype=torch.float32, device="cuda"),
+             "tick": torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")}
+        _abi.check(_abi.lib().mfsgd_grid_export(self.handle, *(_abi.ptr(t[k]) for k in
+                                                ("blk_run_ptr", "run_start", "run_user", "item", "val", "tick")),
+                                                _abi.stream_ptr()))
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in t.items()}
+        out["run_user"], out["item"], out["val"], out["tick"] = out["run_user"][:nr], out["item"][:n], out["val"][:n], out["tick"][:n]
+        return out
+
     def __del__(self):
         try:
             if self.handle:
@@ -216,6 +239,7 @@ class ExplicitMF(Recommender):
                       _abi.ptr(order_log), _abi.stream_ptr()))
 
     def device_errors(self):
+        self._grid.status()
         d = self._dev
         tr = rmse_exact(self._d_samples, None, None, d["P"], d["Q"], d["b_u"], d["b_i"], self.b, None, d["z"])
         te = rmse_exact(self._d_test, None, None, d["P"], d["Q"], d["b_u"], d["b_i"], self.b, None, d["z"])
@@ -245,7 +269,7 @@ class ExplicitMF(Recommender):
                     self.alpha *= 1.06
                 self.previous_mse = tr - .0001
                 self.history.append((done, tr, te, self.alpha))
-        _abi.torch_mod().cuda.synchronize()
+        self._grid.status()
         self._from_dev()
         return self.history
 

@@ -69,7 +69,11 @@ struct SchedView {
     int32_t *row_lock, *counters, *order_log;
     int32_t log_base;  // epoch * Gr * Gc
     uint32_t seed;
+    int32_t *err;      // sticky error word: 1 = ticket wait ran out, 2 = row-lock search ran out
 };
+
+constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
+constexpr int SPIN_LOCK_SWEEPS = 1 << 20;
 
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -241,10 +245,12 @@ template <typename T, int KC, bool STAGE>
 __device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_t c_base, T *__restrict__ P,
                                             T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b,
                                             const T *__restrict__ z, T alpha, T beta1, T beta2, int variant, int k,
-                                            int *tick_done, T *qs, T *bis, int lane)
+                                            int *tick_done, T *qs, T *bis, int lane, int32_t *err)
 {
-    const int32_t u = g.run_user[j];
-    const int32_t t0 = g.run_start[j], t1 = g.run_start[j + 1];
+    // everything that steers control flow is made explicitly wave-uniform (SGPRs, scalar branches)
+    const int32_t u = __builtin_amdgcn_readfirstlane(g.run_user[j]);
+    const int32_t t0 = __builtin_amdgcn_readfirstlane(g.run_start[j]);
+    const int32_t t1 = __builtin_amdgcn_readfirstlane(g.run_start[j + 1]);
     T p[KC], zz[KC], q[KC];
     T *prow = P + (int64_t)u * k;
 #pragma unroll
@@ -259,12 +265,18 @@ __device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_
     // biases are rewritten by other workgroups earlier in this launch: atomic loads never become scalar loads
     T bu = __hip_atomic_load(&b_u[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (int32_t t = t0; t < t1; ++t) {
-        const int32_t ig = g.item[t];
+        const int32_t ig = __builtin_amdgcn_readfirstlane(g.item[t]);
         const int32_t il = ig - c_base;
-        const int32_t tk = g.tick[t];
+        const int32_t tk = __builtin_amdgcn_readfirstlane(g.tick[t]);
         const T r = (T)g.val[t];
-        while (__hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tk)
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                &tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tk; ++spins) {
+            if (spins >= SPIN_TICKET_MAX) {
+                if (lane == 0) atomicOr(err, 1);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         T bi;
         T *qrow = Q + (int64_t)ig * k;
@@ -327,11 +339,12 @@ __device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_
 template <typename T, int KC, bool STAGE>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis)
+                                              int *tick_done, T *qs, T *bis, int32_t *err)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int32_t bid = r * g.Gc + c;
-    const int32_t run_lo = g.blk_run_ptr[bid], run_hi = g.blk_run_ptr[bid + 1];
+    const int32_t run_lo = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid]);
+    const int32_t run_hi = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid + 1]);
     const int32_t c_base = c * g.ibp;
     int32_t width = (int32_t)(g.n_items - c_base);
     if (width > g.ibp) width = g.ibp;
@@ -340,19 +353,20 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     __syncthreads();
     if (g.user_unique) {
         for (;;) {
-            int32_t j = 0;
-            if (lane == 0) j = atomicAdd(&ctl[CTL_RUN], 1);
-            j = __builtin_amdgcn_readfirstlane(j);
+            // branch-free on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around the
+            // branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
+            const int32_t mine = atomicAdd(&ctl[CTL_RUN], lane == 0 ? 1 : 0);
+            const int32_t j = __builtin_amdgcn_readlane(mine, 0);
             if (j >= run_hi) break;
             process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
-                                      qs, bis, lane);
+                                      qs, bis, lane, err);
         }
     } else {
         // a user may own several runs of this block: all of them go to one wave, in stored order
         for (int32_t j = run_lo; j < run_hi; ++j) {
             if ((int)(mix32((uint32_t)g.run_user[j]) % (uint32_t)nw) != wave) continue;
             process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
-                                      qs, bis, lane);
+                                      qs, bis, lane, err);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(1024) void k_epoch_fixed(GridView g, T *P, T *Q, T 
     }
     if (g.blk_run_ptr[r * g.Gc + c] == g.blk_run_ptr[r * g.Gc + c + 1]) return;
     stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
-    process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs, bis);
+    process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs, bis, s.err);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -444,7 +458,8 @@ __global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *
             if (tid == 0) {
                 int32_t found = -1;
                 int32_t remain = ctl[CTL_REMAIN];
-                while (remain > 0 && found < 0) {
+                for (int sweeps = 0; remain > 0 && found < 0; ++sweeps) {
+                    if (sweeps >= SPIN_LOCK_SWEEPS) { atomicOr(s.err, 2); break; }
                     for (int32_t rr = 0; rr < g.Gr; ++rr) {
                         int32_t r = pos + rr;
                         if (r >= g.Gr) r -= g.Gr;
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *
             const int32_t r = ctl[CTL_ROW];
             if (r < 0) break;
             process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
-                                        qs, bis);
+                                        qs, bis, s.err);
             if (tid == 0) {
                 // release: every wave drained its stores before the barrier that ended process_block
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -505,7 +520,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         auto kern = k_epoch_fixed<T, KC, STAGE>;
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
         for (int it = 0; it < iters; ++it) {
-            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed};
+            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8};
             for (int d = 0; d <= gv.Gr + gv.Gc - 2; ++d) {
                 const int r0 = std::max(0, d - (gv.Gc - 1)), r1 = std::min(gv.Gr - 1, d);
                 hipLaunchKernelGGL(kern, dim3(r1 - r0 + 1), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z,
@@ -526,9 +541,9 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     }
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
     for (int it = 0; it < iters; ++it) {
-        MF_HIP(hipMemsetAsync(G->counters, 0, 64, st));
+        MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
         MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
-        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it)};
+        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8};
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2,
                            variant, k, lp, s);
         MF_LAUNCH_CHECK();
@@ -590,6 +605,37 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
     delete g;
 }
 
+int mfsgd_grid_status(mfsgd_grid *g, void *stream)
+{
+    MF_ARG(g, "grid_status: null grid");
+    int32_t h = 0;
+    hipStream_t st = as_stream(stream);
+    MF_HIP(hipMemcpyAsync(&h, g->counters + 8, 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (h) {
+        MF_HIP(hipMemsetAsync(g->counters + 8, 0, 4, st));
+        mfsgd_set_error("epoch kernel gave up waiting (%s%s): results of that run are invalid",
+                        (h & 1) ? "item ticket " : "", (h & 2) ? "row lock" : "");
+        return MFSGD_ERR_GRID;
+    }
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_start, int32_t *run_user, int32_t *item,
+                      float *val, int32_t *tick, void *stream)
+{
+    MF_ARG(g, "grid_export: null grid");
+    hipStream_t st = as_stream(stream);
+    const size_t nb = (size_t)g->info.Gr * g->info.Gc, n = (size_t)g->info.n, nr = (size_t)g->info.n_runs;
+    if (blk_run_ptr) MF_HIP(hipMemcpyAsync(blk_run_ptr, g->blk_run_ptr, (nb + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (run_start) MF_HIP(hipMemcpyAsync(run_start, g->run_start, (nr + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (run_user && nr) MF_HIP(hipMemcpyAsync(run_user, g->run_user, nr * 4, hipMemcpyDeviceToDevice, st));
+    if (item && n) MF_HIP(hipMemcpyAsync(item, g->item, n * 4, hipMemcpyDeviceToDevice, st));
+    if (val && n) MF_HIP(hipMemcpyAsync(val, g->val, n * 4, hipMemcpyDeviceToDevice, st));
+    if (tick && n) MF_HIP(hipMemcpyAsync(tick, g->tick, n * 4, hipMemcpyDeviceToDevice, st));
+    return MFSGD_OK;
+}
+
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info)
 {
     MF_ARG(g && info, "grid_get_info: null pointer");
@@ -621,6 +667,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
     MF_HIP(dalloc(&G->counters, 16));
+    MF_HIP(hipMemsetAsync(G->counters, 0, 64, st));
     std::vector<int32_t> h_blk((size_t)nb + 1, 0);
     if (n == 0) {
         MF_HIP(hipMemsetAsync(G->blk_run_ptr, 0, sizeof(int32_t) * (size_t)(nb + 1), st));

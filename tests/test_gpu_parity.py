@@ -158,6 +158,49 @@ def test_prep_edge_cases(ra):
     assert out.cpu().tolist() == [[0, 0, 1], [0, 1, 3], [1, 5, 2]]
 
 
+# ------------------------------------------------------------------ the block grid (block-local runs + tickets)
+def _expected_grid(s, U, I, ubp, ibp, order):
+    Gr, Gc = -(-U // ubp), -(-I // ibp)
+    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
+    perm = np.lexsort((s[:, 0], key)) if order == 1 else np.argsort(key, kind="stable")
+    ss, ks = s[perm], key[perm]
+    n = len(ss)
+    flag = np.ones(n, bool)
+    flag[1:] = (ks[1:] != ks[:-1]) | (ss[1:, 0] != ss[:-1, 0])
+    run_start = np.concatenate([np.flatnonzero(flag), [n]]).astype(np.int32)
+    run_user = ss[flag, 0]
+    blk_ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
+    run_of = np.cumsum(flag) - 1
+    blk_run_ptr = np.array([run_of[p] if p < n else len(run_user) for p in blk_ptr], dtype=np.int32)
+    tick = np.zeros(n, np.int32)
+    seen = {}
+    for t in range(n):
+        kk = (int(ks[t]), int(ss[t, 1]))
+        tick[t] = seen.get(kk, 0)
+        seen[kk] = tick[t] + 1
+    return dict(blk_run_ptr=blk_run_ptr, run_start=run_start, run_user=run_user, item=ss[:, 1],
+                val=ss[:, 2].astype(np.float32), tick=tick)
+
+
+@pytest.mark.parametrize("tag,order", [("a", 0), ("a", 1), ("shuf", 0), ("shuf", 1), ("ragged", 0)])
+def test_grid_arrays_bit_exact(ra, tag, order):
+    import torch
+    from recommender_amd.SGDRecommender import Grid
+    g = load(f"pipeline_{tag}.npz")
+    s = g["d2_samples"]
+    U, I, nt = int(g["n_users"]), int(g["n_items"]), int(g["n_threads"])
+    ubp, ibp = U // (nt + 1) + 1, I // (nt + 1) + 1
+    gr = Grid(torch.from_numpy(s).cuda(), U, I, ubp, ibp, order=order)
+    got, exp = gr.export(), _expected_grid(s, U, I, ubp, ibp, order)
+    for name in exp:
+        np.testing.assert_array_equal(got[name], exp[name], err_msg=name)
+    users_twice = any(len(set(exp["run_user"][a:b])) < b - a
+                      for a, b in zip(exp["blk_run_ptr"][:-1], exp["blk_run_ptr"][1:]))
+    assert gr.info.user_unique == (0 if users_twice else 1)
+    if order == 0:      # reference order: the stored rows are exactly the reference's concatenated blocks
+        np.testing.assert_array_equal(got["item"], g["blocks_concat"][:, 1])
+
+
 # ------------------------------------------------------------------ G8: fixed block order, whole model
 @pytest.mark.parametrize("tag", ["a", "b", "shuf"])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
