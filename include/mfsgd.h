@@ -125,6 +125,9 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
 /* Synchronises and reports whether an epoch kernel ran out of patience on a wait (every spin in the
  * kernels is bounded); clears the flag. */
 int mfsgd_grid_status(mfsgd_grid *g, void *stream);
+/* Profiling aid: for every item stripe c, h_out[3c..3c+2] (HOST) = {ratings in the stripe, start, end} of its
+ * tenure in the most recent free-block epoch, in ticks of the 100 MHz device realtime clock.  Synchronises. */
+int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_out, void *stream);
 
 /* schedule 0 = fixed: equals `iters` passes over the blocks in row-major order, each block walked in
  *               stored order (the deterministic fixed-block-order mode);

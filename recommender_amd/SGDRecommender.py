@@ -33,6 +33,44 @@ from .SubSample import SubSample
 _IMPLICIT = {"none": 0, "frozen": 1, "full": 2}
 
 
+def balanced_permutation(deg, width):
+    """new_id[old_id] such that the stripes [s*width, (s+1)*width) of the new numbering carry near-equal
+    sums of `deg`: ids by decreasing degree, each to the least-loaded stripe that still has a free slot."""
+    import heapq
+    deg = np.asarray(deg)
+    N = len(deg)
+    G = -(-N // width)
+    cap = [width] * (G - 1) + [N - (G - 1) * width]
+    order = np.argsort(-deg, kind="stable")
+    new_id = np.empty(N, dtype=np.int64)
+    if N <= (1 << 21):
+        heap = [(0, s) for s in range(G)]
+        used = [0] * G
+        dl = deg[order].tolist()
+        for old, d in zip(order.tolist(), dl):
+            load, s = heapq.heappop(heap)
+            new_id[old] = s * width + used[s]
+            used[s] += 1
+            if used[s] < cap[s]:
+                heapq.heappush(heap, (load + d, s))
+    else:       # boustrophedon deal: rank r -> stripe r mod G, direction flipping every round
+        rnk = np.arange(N)
+        rnd, pos = rnk // G, rnk % G
+        stripe = np.where(rnd % 2 == 0, pos, G - 1 - pos)
+        # the last stripe may be narrower: overflow there is re-dealt to the stripes with free slots
+        slot = np.zeros(N, dtype=np.int64)
+        for s_ in range(G):
+            idx = np.flatnonzero(stripe == s_)
+            slot[idx] = np.arange(len(idx))
+        over = slot >= np.asarray(cap)[stripe]
+        if over.any():
+            free = [(s_, c_) for s_ in range(G) for c_ in range(int((stripe == s_).sum() - (over & (stripe == s_)).sum()), cap[s_])]
+            for t_, (s_, c_) in zip(np.flatnonzero(over), free):
+                stripe[t_], slot[t_] = s_, c_
+        new_id[order] = stripe * width + slot
+    return new_id
+
+
 class Grid:
     """Owner of a device block grid (mfsgd_grid_*)."""
 
@@ -127,6 +165,22 @@ class ExplicitMF(Recommender):
         self.y_owner = False
         self.b_u = np.zeros(self.n_users)
         self.b_i = np.zeros(self.n_items)
+        self.b = float(self._d_samples[:, 2].double().mean().item())
+
+    def init_params_device(self, seed=0):
+        """Same distributions as init_params, drawn on the GPU (for inputs too large to draw on the host:
+        not the legacy-RNG stream, so not comparable draw by draw with the reference)."""
+        torch = _abi.torch_mod()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(int(seed))
+        k = self.n_factors
+        dt = torch.float64 if self.dtype == "float64" else torch.float32
+        self.P = torch.randn(self.n_users, k, device="cuda", dtype=dt, generator=g) / k
+        self.Q = torch.randn(self.n_items, k, device="cuda", dtype=dt, generator=g) / k
+        self.y = torch.randn(self.n_items, k, device="cuda", dtype=dt, generator=g) / k
+        self.y_owner = False
+        self.b_u = torch.zeros(self.n_users, device="cuda", dtype=dt)
+        self.b_i = torch.zeros(self.n_items, device="cuda", dtype=dt)
         self.b = float(self._d_samples[:, 2].double().mean().item())
 
     def train(self, iters, multithreaded=True, run=True):
@@ -312,12 +366,27 @@ class ExplicitMF(Recommender):
     def random_renumber_samples(self):
         """SGDRecommender.py:228-268: shuffle item ids, then user ids (legacy global RNG, this order), remap
         train and test on the GPU, drop test rows whose user or item is unseen in train, rebuild the CSR."""
-        torch = _abi.torch_mod()
         col_index = np.arange(self.n_items)
         row_index = np.arange(self.n_users)
         np.random.shuffle(col_index)
         np.random.shuffle(row_index)
-        self.col_perm, self.row_perm = col_index.astype(np.int32), row_index.astype(np.int32)
+        self._apply_renumbering(row_index, col_index)
+
+    def balanced_renumber_samples(self):
+        """Throughput-mode alternative to the random shuffle: a permutation that deals users and items into
+        the equal-width stripes of the block grid so that the stripes carry about equal numbers of ratings
+        (longest-processing-time packing).  The reference relies on the random shuffle alone for balance
+        (SGDRecommender.py:228-232); with thousands of stripes a popular item would otherwise share its stripe
+        with other popular items and that stripe's serial chain would set the epoch time."""
+        torch = _abi.torch_mod()
+        ubp, ibp = self._choose_grid()
+        du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
+        di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
+        self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp))
+
+    def _apply_renumbering(self, row_index, col_index):
+        torch = _abi.torch_mod()
+        self.col_perm, self.row_perm = np.asarray(col_index).astype(np.int32), np.asarray(row_index).astype(np.int32)
         d_rp, d_cp = _abi.to_device(self.row_perm, "int32"), _abi.to_device(self.col_perm, "int32")
         lib = _abi.lib()
         before = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).sort().values

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mfsgd_grid_status": (C.c_int, [c_vp, c_vp]),
+    "mfsgd_grid_col_times": (C.c_int, [c_vp, c_vp, c_vp]),
     "mfsgd_hip_epoch_f32": (C.c_int, _sig_epoch(c_f32)),
     "mfsgd_hip_epoch_f64": (C.c_int, _sig_epoch(c_f64)),
 }

@@ -31,6 +31,7 @@
 #include "common.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -51,8 +52,10 @@ struct mfsgd_grid {
     int32_t *col_order = nullptr;  // item stripes, heaviest first
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
+    long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
     int32_t n_cols_nonempty = 0;
     int device = 0;
+    std::vector<int64_t> col_nnz;
 };
 
 namespace {
@@ -70,6 +73,8 @@ struct SchedView {
     int32_t log_base;  // epoch * Gr * Gc
     uint32_t seed;
     int32_t *err;      // sticky error word: 1 = ticket wait ran out, 2 = row-lock search ran out
+    long long *col_clock;
+    int32_t dbg;       // MFSGD_DEBUG_FLAGS (timing experiments only; results are invalid when non-zero)
 };
 
 constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
@@ -213,8 +218,19 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------ epoch kernel
-constexpr int CTL_WORDS = 16;
-enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3 };
+constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
+enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_SINK = 16 };
+
+// "Only lane 0 does X" is written WITHOUT a branch everywhere in this file: every lane executes the store or
+// atomic, lane 0 on the real address and lane l>0 on its own sink word in LDS.  Reason (seen in the gfx950
+// ISA, twice): hipcc threads lanes 1..63 around an `if (lane == 0)` whose result feeds a broadcast or sits
+// at a loop head/latch, re-enters the loop body with part of the wave, and the body - including its
+// s_barrier, DPP and readlane instructions - then runs twice per iteration for that wave.
+template <typename U>
+__device__ __forceinline__ U *sink_ptr(U *real, int *ctl, int lane)
+{
+    return lane == 0 ? real : (U *)(ctl + CTL_SINK + 2 * (lane & 63));
+}
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x)
 {
@@ -241,43 +257,96 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     return p;
 }
 
-template <typename T, int KC, bool STAGE>
-__device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_t c_base, T *__restrict__ P,
-                                            T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b,
-                                            const T *__restrict__ z, T alpha, T beta1, T beta2, int variant, int k,
-                                            int *tick_done, T *qs, T *bis, int lane, int32_t *err)
+// Stage 1 of a run: which run, whose, and where its ratings are (wave-uniform words).
+struct RunIdx {
+    int32_t j, u, t0, t1;
+};
+
+// Stage 2: the user's row (+ implicit term, bias) and the first 64 ratings of the run, one rating per lane.
+template <typename T, int KC> struct RunHead {
+    int32_t u, t0, t1;
+    T p[KC], zz[KC], bu;
+    int32_t m_item, m_tick;
+    float m_val;
+};
+
+__device__ __forceinline__ void run_index(const GridView &g, int32_t j, RunIdx &x)
 {
     // everything that steers control flow is made explicitly wave-uniform (SGPRs, scalar branches)
-    const int32_t u = __builtin_amdgcn_readfirstlane(g.run_user[j]);
-    const int32_t t0 = __builtin_amdgcn_readfirstlane(g.run_start[j]);
-    const int32_t t1 = __builtin_amdgcn_readfirstlane(g.run_start[j + 1]);
-    T p[KC], zz[KC], q[KC];
-    T *prow = P + (int64_t)u * k;
+    x.j = j;
+    x.u = __builtin_amdgcn_readfirstlane(g.run_user[j]);
+    x.t0 = __builtin_amdgcn_readfirstlane(g.run_start[j]);
+    x.t1 = __builtin_amdgcn_readfirstlane(g.run_start[j + 1]);
+}
+
+// one coalesced load per array brings the metadata of ratings [t, t+64) of a run, lane l holding rating t+l
+__device__ __forceinline__ void load_meta(const GridView &g, int32_t t, int32_t t1, int lane, int32_t &m_item,
+                                          int32_t &m_tick, float &m_val)
+{
+    const int32_t tt = t + lane < t1 ? t + lane : t1 - 1;
+    m_item = g.item[tt];
+    m_tick = g.tick[tt];
+    m_val = g.val[tt];
+}
+
+// Issues the loads of a run's head; nothing here waits, so a caller can keep two runs in flight behind the
+// one it is walking and the HBM latency of the row and of the metadata hides behind that walk.
+template <typename T, int KC>
+__device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, const T *__restrict__ P,
+                                         const T *__restrict__ b_u, const T *__restrict__ z, int k, int lane,
+                                         RunHead<T, KC> &h)
+{
+    h.u = x.u; h.t0 = x.t0; h.t1 = x.t1;
+    const T *prow = P + (int64_t)h.u * k;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int f = lane + 64 * c;
-        p[c] = 0; zz[c] = 0;
+        h.p[c] = 0; h.zz[c] = 0;
         if (f < k) {
-            p[c] = prow[f];
-            if (z) zz[c] = z[(int64_t)u * k + f];
+            h.p[c] = prow[f];
+            if (z) h.zz[c] = z[(int64_t)h.u * k + f];
         }
     }
     // biases are rewritten by other workgroups earlier in this launch: atomic loads never become scalar loads
-    T bu = __hip_atomic_load(&b_u[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    h.bu = __hip_atomic_load(&b_u[h.u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    load_meta(g, h.t0, h.t1, lane, h.m_item, h.m_tick, h.m_val);
+}
+
+template <typename T, int KC, bool STAGE>
+__device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
+                                         T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
+                                         T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
+                                         T *bis, int lane, int32_t *err)
+{
+    const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
+    T p[KC], zz[KC], q[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) { p[c] = h.p[c]; zz[c] = h.zz[c]; }
+    T bu = h.bu;
+    int32_t m_item = h.m_item, m_tick = h.m_tick;
+    float m_val = h.m_val;
+    T *prow = P + (int64_t)u * k;
     for (int32_t t = t0; t < t1; ++t) {
-        const int32_t ig = __builtin_amdgcn_readfirstlane(g.item[t]);
+        const int32_t slot = (t - t0) & 63;
+        if (slot == 0 && t != t0) load_meta(g, t, t1, lane, m_item, m_tick, m_val);  // runs longer than 64
+        const int32_t ig = __builtin_amdgcn_readlane(m_item, slot);
         const int32_t il = ig - c_base;
-        const int32_t tk = __builtin_amdgcn_readfirstlane(g.tick[t]);
-        const T r = (T)g.val[t];
+        const int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
+        const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
         for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                 &tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tk; ++spins) {
             if (spins >= SPIN_TICKET_MAX) {
-                if (lane == 0) atomicOr(err, 1);
+                atomicOr(err, 1);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (spins > 8) __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // STAGE: ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in
+        // issue order, so ordering needs no wait at all - only the compiler must keep program order (a
+        // workgroup-scope fence over all address spaces would also drain vmcnt, i.e. stall the item's chain
+        // on this wave's prefetched HBM loads).  Otherwise Q is in global memory: full workgroup fences.
+        if (STAGE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         T bi;
         T *qrow = Q + (int64_t)ig * k;
         if (STAGE) {
@@ -314,24 +383,25 @@ __device__ __forceinline__ void process_run(const GridView &g, int32_t j, int32_
                 const int f = lane + 64 * c;
                 if (f < k) qs[(size_t)il * k + f] = q[c];
             }
-            if (lane == 0) bis[il] = bi;
+            *sink_ptr(&bis[il], ctl, lane) = bi;
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 const int f = lane + 64 * c;
                 if (f < k) qrow[f] = q[c];
             }
-            if (lane == 0) __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&tick_done[il], tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (STAGE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(sink_ptr(&tick_done[il], ctl, lane), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int f = lane + 64 * c;
         if (f < k) prow[f] = p[c];
     }
-    if (lane == 0) __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
 }
 
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
@@ -349,24 +419,47 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     int32_t width = (int32_t)(g.n_items - c_base);
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
-    if (tid == 0) ctl[CTL_RUN] = run_lo;
+    ctl[CTL_RUN] = run_lo;  // every thread, same value
     __syncthreads();
     if (g.user_unique) {
-        for (;;) {
-            // branch-free on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around the
-            // branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
-            const int32_t mine = atomicAdd(&ctl[CTL_RUN], lane == 0 ? 1 : 0);
-            const int32_t j = __builtin_amdgcn_readlane(mine, 0);
-            if (j >= run_hi) break;
-            process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
-                                      qs, bis, lane, err);
+        // branch-free dequeue on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around
+        // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
+        // Three runs in flight per wave: walking `cur`, head loads of `nxt` issued, index words of `far`
+        // issued.  Runs are handed out in stored order and a wave finishes a run before it walks the next
+        // one it claimed, so the earliest unfinished rating is always being walked: ticket waits cannot
+        // deadlock however far ahead the claims run.
+        auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
+        RunHead<T, KC> cur, nxt;
+        RunIdx xn{}, xf{};
+        int32_t j = claim();
+        if (j < run_hi) {
+            RunIdx x0;
+            run_index(g, j, x0);
+            load_run<T, KC>(g, x0, P, b_u, z, k, lane, cur);
+        }
+        int32_t jn = j < run_hi ? claim() : run_hi;
+        if (jn < run_hi) run_index(g, jn, xn);
+        while (j < run_hi) {
+            const int32_t jf = jn < run_hi ? claim() : run_hi;
+            if (jf < run_hi) run_index(g, jf, xf);
+            if (jn < run_hi) load_run<T, KC>(g, xn, P, b_u, z, k, lane, nxt);
+            walk_run<T, KC, STAGE>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl, tick_done,
+                                   qs, bis, lane, err);
+            cur = nxt;
+            xn = xf;
+            j = jn;
+            jn = jf;
         }
     } else {
         // a user may own several runs of this block: all of them go to one wave, in stored order
         for (int32_t j = run_lo; j < run_hi; ++j) {
             if ((int)(mix32((uint32_t)g.run_user[j]) % (uint32_t)nw) != wave) continue;
-            process_run<T, KC, STAGE>(g, j, c_base, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, tick_done,
-                                      qs, bis, lane, err);
+            RunHead<T, KC> cur;
+            RunIdx x;
+            run_index(g, j, x);
+            load_run<T, KC>(g, x, P, b_u, z, k, lane, cur);
+            walk_run<T, KC, STAGE>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl, tick_done,
+                                   qs, bis, lane, err);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -403,7 +496,7 @@ __device__ __forceinline__ void stripe_store(const GridView &g, int32_t c, T *Q,
 
 // schedule 0: one launch per anti-diagonal d; workgroup w does block (r0 + w, d - r0 - w)
 template <typename T, int KC, bool STAGE>
-__global__ __launch_bounds__(1024) void k_epoch_fixed(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+__global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                       T beta1, T beta2, int variant, int k, int d, int r0,
                                                       LdsPlan<T> lp, SchedView s)
 {
@@ -412,8 +505,8 @@ __global__ __launch_bounds__(1024) void k_epoch_fixed(GridView g, T *P, T *Q, T 
     int *tick_done = (int *)(smem + lp.tick);
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
     const int32_t r = r0 + (int32_t)blockIdx.x, c = d - r;
-    if (s.order_log && threadIdx.x == 0) {
-        // row-major position: the fixed schedule's log is the row-major order itself
+    if (s.order_log) {
+        // every thread, same values.  row-major position: the fixed schedule's log is the row-major order itself
         s.order_log[2 * (s.log_base + r * g.Gc + c)] = r;
         s.order_log[2 * (s.log_base + r * g.Gc + c) + 1] = c;
     }
@@ -425,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_epoch_fixed(GridView g, T *P, T *Q, T 
 
 // schedule 1: persistent workgroups, column tenure + row locks
 template <typename T, int KC, bool STAGE>
-__global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+__global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,15 +526,24 @@ __global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *
     int *tick_done = (int *)(smem + lp.tick);
     unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
+    // selects wave 0 is scalar, and nothing inside is predicated per lane (sink_ptr).
+    const bool sched_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     for (;;) {
-        if (tid == 0) {
-            const int32_t ci = __hip_atomic_fetch_add(&s.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ctl[CTL_COL] = ci < g.n_cols ? g.col_order[ci] : -1;
+        if (sched_wave) {
+            const int32_t ci = __builtin_amdgcn_readlane(
+                __hip_atomic_fetch_add(sink_ptr(&s.counters[0], ctl, lane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
+            int32_t col = -1;
+            if (ci < g.n_cols) {
+                col = __builtin_amdgcn_readfirstlane(g.col_order[ci]);
+                s.col_clock[2 * col] = (long long)__builtin_amdgcn_s_memrealtime();
+            }
+            ctl[CTL_COL] = col;
             ctl[CTL_REMAIN] = 0;
         }
         __syncthreads();
-        const int32_t c = ctl[CTL_COL];
+        const int32_t c = __builtin_amdgcn_readfirstlane(ctl[CTL_COL]);
         if (c < 0) break;
         // rows with an empty block need no visit
         int32_t mine = 0;
@@ -450,39 +552,48 @@ __global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *
             row_done[r] = empty ? 1 : 0;
             mine += empty ? 0 : 1;
         }
-        if (mine) atomicAdd(&ctl[CTL_REMAIN], mine);
+        atomicAdd(&ctl[CTL_REMAIN], mine);
         stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
         for (;;) {
-            if (tid == 0) {
+            if (sched_wave) {
                 int32_t found = -1;
-                int32_t remain = ctl[CTL_REMAIN];
+                const int32_t remain = __builtin_amdgcn_readfirstlane(ctl[CTL_REMAIN]);
                 for (int sweeps = 0; remain > 0 && found < 0; ++sweeps) {
                     if (sweeps >= SPIN_LOCK_SWEEPS) { atomicOr(s.err, 2); break; }
-                    for (int32_t rr = 0; rr < g.Gr; ++rr) {
-                        int32_t r = pos + rr;
-                        if (r >= g.Gr) r -= g.Gr;
-                        if (row_done[r]) continue;
-                        int32_t expect = 0;
-                        if (__hip_atomic_compare_exchange_strong(&s.row_lock[r], &expect, 1, __ATOMIC_RELAXED,
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            found = r;
-                            row_done[r] = 1;
-                            pos = r + 1 == g.Gr ? 0 : r + 1;
-                            break;
+                    // 64 rows per step: every lane looks at one row of the rotation that starts at `pos`
+                    for (int32_t base = 0; base < g.Gr && found < 0; base += 64) {
+                        int32_t r = pos + base + lane;
+                        while (r >= g.Gr) r -= g.Gr;
+                        const bool cand = base + lane < g.Gr && !row_done[r];
+                        unsigned long long mask = __ballot(cand);
+                        while (mask != 0 && found < 0) {
+                            const int l = __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            const int32_t rc = __builtin_amdgcn_readlane(r, l);
+                            // one real CAS (lane 0); the other lanes hit their own sink words
+                            int32_t expect = 0;
+                            int32_t *w = sink_ptr(&s.row_lock[rc], ctl, lane);
+                            if (lane != 0) expect = 0x7fffffff;   // value select, not control flow
+                            __hip_atomic_compare_exchange_strong(w, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                            if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;   // unchanged <=> swapped
                         }
                     }
                     if (found < 0) __builtin_amdgcn_s_sleep(32);
                 }
                 if (found >= 0) {
+                    row_done[found] = 1;
+                    pos = found + 1 == g.Gr ? 0 : found + 1;
                     ctl[CTL_REMAIN] = remain - 1;
                     // acquire: drop this CU's L1 so that the previous holder's P rows are re-read
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (!(s.dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (s.order_log) {
-                        const int32_t slot =
-                            __hip_atomic_fetch_add(&s.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int32_t slot = __builtin_amdgcn_readlane(
+                            __hip_atomic_fetch_add(sink_ptr(&s.counters[1], ctl, lane), 1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT), 0);
                         s.order_log[2 * (s.log_base + slot)] = found;
                         s.order_log[2 * (s.log_base + slot) + 1] = c;
                     }
@@ -490,18 +601,20 @@ __global__ __launch_bounds__(1024) void k_epoch_free(GridView g, T *P, T *Q, T *
                 ctl[CTL_ROW] = found;
             }
             __syncthreads();
-            const int32_t r = ctl[CTL_ROW];
+            const int32_t r = __builtin_amdgcn_readfirstlane(ctl[CTL_ROW]);
             if (r < 0) break;
-            process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
-                                        qs, bis, s.err);
-            if (tid == 0) {
+            if (!(s.dbg & 4))
+                process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl,
+                                            tick_done, qs, bis, s.err);
+            if (sched_wave) {
                 // release: every wave drained its stores before the barrier that ended process_block
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&s.row_lock[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
+        if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -512,7 +625,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
 {
     const bool dynamic = schedule == 1;
     const LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic);
-    if (waves <= 0) waves = 8;
+    if (waves <= 0) waves = 16;
     if (waves > 16) waves = 16;
     const int threads = waves * 64;
     const int64_t nb = (int64_t)gv.Gr * gv.Gc;
@@ -520,7 +633,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         auto kern = k_epoch_fixed<T, KC, STAGE>;
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
         for (int it = 0; it < iters; ++it) {
-            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8};
+            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8, G->col_clock, 0};
             for (int d = 0; d <= gv.Gr + gv.Gc - 2; ++d) {
                 const int r0 = std::max(0, d - (gv.Gc - 1)), r1 = std::min(gv.Gr - 1, d);
                 hipLaunchKernelGGL(kern, dim3(r1 - r0 + 1), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z,
@@ -531,6 +644,8 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         return MFSGD_OK;
     }
     auto kern = k_epoch_free<T, KC, STAGE>;
+    const char *dbg_env = getenv("MFSGD_DEBUG_FLAGS");
+    const int32_t dbg = dbg_env ? atoi(dbg_env) : 0;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     hipDeviceProp_t prop;
     MF_HIP(hipGetDeviceProperties(&prop, G->device));
@@ -543,7 +658,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     for (int it = 0; it < iters; ++it) {
         MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
         MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
-        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8};
+        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8, G->col_clock, dbg};
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2,
                            variant, k, lp, s);
         MF_LAUNCH_CHECK();
@@ -599,7 +714,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters};
+                    g->counters, g->col_clock};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -636,6 +751,22 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
     return MFSGD_OK;
 }
 
+int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *stream)
+{
+    MF_ARG(g && h_nnz_start_end, "grid_col_times: null pointer");
+    hipStream_t st = as_stream(stream);
+    const size_t Gc = (size_t)g->info.Gc;
+    std::vector<long long> clk(2 * Gc);
+    MF_HIP(hipMemcpyAsync(clk.data(), g->col_clock, sizeof(long long) * 2 * Gc, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    for (size_t c = 0; c < Gc; ++c) {
+        h_nnz_start_end[3 * c] = g->col_nnz.empty() ? 0 : g->col_nnz[c];
+        h_nnz_start_end[3 * c + 1] = clk[2 * c];
+        h_nnz_start_end[3 * c + 2] = clk[2 * c + 1];
+    }
+    return MFSGD_OK;
+}
+
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info)
 {
     MF_ARG(g && info, "grid_get_info: null pointer");
@@ -667,6 +798,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
     MF_HIP(dalloc(&G->counters, 16));
+    MF_HIP(dalloc(&G->col_clock, (size_t)Gc * 2));
+    MF_HIP(hipMemsetAsync(G->col_clock, 0, sizeof(long long) * 2 * (size_t)Gc, st));
     MF_HIP(hipMemsetAsync(G->counters, 0, 64, st));
     std::vector<int32_t> h_blk((size_t)nb + 1, 0);
     if (n == 0) {
@@ -803,6 +936,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     int32_t ne = 0;
     while (ne < Gc && col_nnz[ord[ne]] > 0) ++ne;
     G->n_cols_nonempty = ne;
+    G->col_nnz = col_nnz;
     G->info.max_block = max_block;
     G->info.max_col_nnz = *std::max_element(col_nnz.begin(), col_nnz.end());
     G->info.max_row_nnz = *std::max_element(row_nnz.begin(), row_nnz.end());

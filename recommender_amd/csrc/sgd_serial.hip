@@ -61,21 +61,22 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_sgd_serial(
             pf[c] = 0; qf[c] = 0;
             if (f < k) { pf[c] = p[f]; qf[c] = q[f]; part += qf[c] * (pf[c] + ys[c]); }
         }
-        // biases live with thread 0 only: it folds them into its partial, so the reduced sum is the
-        // whole prediction and nobody else ever loads a word that thread 0 rewrites.
-        T bu = 0, bi = 0;
-        if (tid == 0) { bu = b_u[ug - u_off]; bi = b_i[ig - i_off]; }
+        // Biases: every thread loads them (one address per wave: a broadcast), every thread computes the
+        // same e and every thread stores the same new values - no `if (tid == 0)` inside a loop with a
+        // barrier (hipcc may re-enter such a loop body with part of a wave, see epoch.hip sink_ptr), and no
+        // extra barrier: a thread's own store precedes its own later load of that word, and all stores of
+        // one rating carry identical bits.
+        const T bu = __hip_atomic_load(&b_u[ug - u_off], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const T bi = __hip_atomic_load(&b_i[ig - i_off], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         part = wave_sum(part);
-        if ((tid & 63) == 0) s_red[t & 1][wave] = part + (bu + bi);
+        s_red[t & 1][wave] = part;   // all lanes of the wave, same value
         __syncthreads();  // the only barrier per rating (the slot is reused two ratings later)
-        T pred = b;
+        T pred = b + bu + bi;
 #pragma unroll
         for (int w = 0; w < SERIAL_THREADS / 64; ++w) pred += s_red[t & 1][w];
         const T e = r - pred;
-        if (tid == 0) {
-            b_u[ug - u_off] = bu + alpha * (e - beta1 * bu);
-            b_i[ig - i_off] = bi + alpha * (e - beta1 * bi);
-        }
+        __hip_atomic_store(&b_u[ug - u_off], bu + alpha * (e - beta1 * bu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&b_i[ig - i_off], bi + alpha * (e - beta1 * bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (variant == 0) {
 #pragma unroll
             for (int c = 0; c < SERIAL_MAXF; ++c) {
