@@ -230,15 +230,23 @@ class ExplicitMF(Recommender):
     # ------------------------------------------------------------------ the GPU FPSGD path
     def _choose_grid(self):
         """Throughput grid: item stripes narrow enough for the Q stripe (+b_i, tickets) to sit in LDS next
-        to the scheduler words, at least ~2 stripes per workgroup; user stripes ~4x the workgroups."""
+        to the scheduler words, up to 512 item stripes (two 16-wave workgroups per CU) and 1024 user
+        stripes, shrunk together for small inputs so that a block still holds ~128 ratings (the
+        per-block cost - lock, fences, barriers - is a few microseconds)."""
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
             k = self.n_factors
             esz = 8 if self.dtype == "float64" else 4
             ibp_max = max(1, (144 * 1024) // ((k + 1) * esz + 4))
-            Gc = max(-(-self.n_items // ibp_max), min(self.n_items, 512))
-            Gr = min(self.n_users, 1024)
+            Gc_min = -(-self.n_items // ibp_max)
+            Gc, Gr = min(self.n_items, 512), min(self.n_users, 1024)
+            n = int(self._d_samples.shape[0])
+            want = max(1.0, n / 128.0)
+            if Gr * Gc > want:
+                f = (want / (Gr * Gc)) ** 0.5
+                Gr, Gc = max(1, int(Gr * f)), max(1, int(Gc * f))
+            Gc = min(self.n_items, max(Gc, Gc_min))
         ubp = -(-self.n_users // Gr)
         ibp = -(-self.n_items // Gc)
         return ubp, ibp

@@ -272,11 +272,13 @@ template <typename T, int KC> struct RunHead {
 
 __device__ __forceinline__ void run_index(const GridView &g, int32_t j, RunIdx &x)
 {
-    // everything that steers control flow is made explicitly wave-uniform (SGPRs, scalar branches)
+    // Loaded with VECTOR loads on purpose (atomic loads are never turned into s_load): scalar loads share
+    // lgkmcnt with the LDS traffic of the run being walked and return out of order, so the first ticket poll
+    // of the current run would otherwise wait for these far-ahead loads (an HBM round trip per run).
     x.j = j;
-    x.u = __builtin_amdgcn_readfirstlane(g.run_user[j]);
-    x.t0 = __builtin_amdgcn_readfirstlane(g.run_start[j]);
-    x.t1 = __builtin_amdgcn_readfirstlane(g.run_start[j + 1]);
+    x.u = __hip_atomic_load(&g.run_user[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    x.t0 = __hip_atomic_load(&g.run_start[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    x.t1 = __hip_atomic_load(&g.run_start[j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // one coalesced load per array brings the metadata of ratings [t, t+64) of a run, lane l holding rating t+l
@@ -296,7 +298,10 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
                                          const T *__restrict__ b_u, const T *__restrict__ z, int k, int lane,
                                          RunHead<T, KC> &h)
 {
-    h.u = x.u; h.t0 = x.t0; h.t1 = x.t1;
+    // everything that steers control flow is made explicitly wave-uniform (SGPRs, scalar branches)
+    h.u = __builtin_amdgcn_readfirstlane(x.u);
+    h.t0 = __builtin_amdgcn_readfirstlane(x.t0);
+    h.t1 = __builtin_amdgcn_readfirstlane(x.t1);
     const T *prow = P + (int64_t)h.u * k;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {

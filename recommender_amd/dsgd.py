@@ -1,0 +1,202 @@
+"""Multi-GPU DSGD on top of the single-GPU FPSGD epoch kernel: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+No counterpart in the reference (it has no multi-device path); the block-exclusivity
+rule it implements is the same FPSGD invariant (RayBlockScheduler.py:50-62) one level up:
+
+  * users are cut into `world` contiguous super-stripes, items into `world` contiguous shards, both on
+    stripe boundaries of the block grid;
+  * rank g owns the P / b_u rows of user super-stripe g for good and only ever sees the ratings of those
+    users, bucketed by item shard (one block grid per shard);
+  * an epoch is `world` sub-epochs; in sub-epoch s rank g runs the free-block epoch kernel on the
+    super-block (g, (g+s) mod world) - no two ranks touch the same user or item rows - and then the ring
+    turns: every rank sends the Q / b_i rows of the shard it has just updated to rank g-1 and receives the
+    next shard from rank g+1 (paired send/recv, in place, no host staging, no all-reduce);
+  * held-out RMSE: shard owners broadcast their rows, every rank sums squared errors over its own users,
+    one all-reduce of four numbers.
+
+The plan (who holds what when) is pure Python and runs anywhere; the compute step is a callable, so the
+CPU tests drive the same ring with the oracle's block kernel under gloo.
+"""
+import time
+
+import numpy as np
+
+
+class DSGDPlan:
+    def __init__(self, n_users, n_items, world, ubp, ibp):
+        self.n_users, self.n_items, self.world, self.ubp, self.ibp = n_users, n_items, world, ubp, ibp
+        self.Gr, self.Gc = -(-n_users // ubp), -(-n_items // ibp)
+        rows = -(-self.Gr // world)          # row stripes per rank
+        cols = -(-self.Gc // world)          # column stripes per shard
+        self.user_edges = [min(n_users, g * rows * ubp) for g in range(world + 1)]
+        self.item_edges = [min(n_items, q * cols * ibp) for q in range(world + 1)]
+        self.user_edges[-1], self.item_edges[-1] = n_users, n_items
+
+    def shard_at(self, rank, step):
+        """Item shard that `rank` holds (and updates) in sub-epoch `step`."""
+        return (rank + step) % self.world
+
+    def send_to(self, rank):
+        return (rank - 1) % self.world
+
+    def recv_from(self, rank):
+        return (rank + 1) % self.world
+
+    def user_range(self, rank):
+        return self.user_edges[rank], self.user_edges[rank + 1]
+
+    def item_range(self, shard):
+        return self.item_edges[shard], self.item_edges[shard + 1]
+
+    def serial_order(self):
+        """The (rank, shard) super-blocks of one epoch in an order a single worker could replay:
+        sub-epoch by sub-epoch (the blocks inside one sub-epoch share no rows and no columns)."""
+        return [(g, self.shard_at(g, s)) for s in range(self.world) for g in range(self.world)]
+
+
+def ring_epoch(plan, rank, Q, b_i, compute, dist=None):
+    """One DSGD epoch on this rank: world x (compute on the held shard; pass it on, take the next one).
+    `compute(shard)` updates P/b_u of this rank's users and the shard's rows of Q/b_i in place."""
+    W = plan.world
+    for s in range(W):
+        q = plan.shard_at(rank, s)
+        compute(q)
+        if W == 1:
+            continue
+        nq = plan.shard_at(rank, s + 1)
+        a0, a1 = plan.item_range(q)
+        r0, r1 = plan.item_range(nq)
+        ops = [dist.P2POp(dist.isend, Q[a0:a1], plan.send_to(rank)),
+               dist.P2POp(dist.isend, b_i[a0:a1], plan.send_to(rank)),
+               dist.P2POp(dist.irecv, Q[r0:r1], plan.recv_from(rank)),
+               dist.P2POp(dist.irecv, b_i[r0:r1], plan.recv_from(rank))]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def gather_items(plan, rank, Q, b_i, dist):
+    """After a whole epoch shard q is current on rank q: everyone fetches every shard (evaluation only)."""
+    for q in range(plan.world):
+        a0, a1 = plan.item_range(q)
+        if a1 > a0:
+            dist.broadcast(Q[a0:a1], src=q)
+            dist.broadcast(b_i[a0:a1], src=q)
+
+
+def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4):
+    """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~64+ ratings, with
+    up to 256 column stripes per shard (one workgroup each) and twice as many row stripes as columns."""
+    ibp_max = max(1, (144 * 1024) // ((k + 1) * esz + 4))
+    cols = min(256, max(1, n_items // world))
+    rows = min(2 * cols, max(1, n_users // world))
+    per = n_train / float(world * world)
+    want = max(1.0, per / 64.0)
+    if rows * cols > want:
+        f = (want / (rows * cols)) ** 0.5
+        rows, cols = max(1, int(rows * f)), max(1, int(cols * f))
+    ibp = max(1, min(ibp_max, -(-n_items // (cols * world))))
+    ubp = max(1, -(-n_users // (rows * world)))
+    return ubp, ibp
+
+
+def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
+    """bench.py's multi-GPU leg (strong scaling: the same data set on 1..N GPUs)."""
+    import json
+    import torch
+    import torch.distributed as dist
+    from . import _abi
+    from .SGDRecommender import Grid, balanced_permutation
+    from .numba_methods import rmse_exact
+
+    alpha, beta1, beta2 = hp
+    train, test, U, I, k = data
+    n_train_total = int(train.shape[0])
+    if args.grid:
+        Gr, Gc = (int(x) for x in args.grid.split(","))
+        ubp, ibp = -(-U // Gr), -(-I // Gc)
+    else:
+        ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k)
+    t0 = time.perf_counter()
+    # the same load-balancing permutation on every rank (identical inputs, deterministic algorithm)
+    du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
+    di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
+    rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
+    cp = torch.from_numpy(balanced_permutation(di, ibp).astype(np.int32)).cuda()
+    lib = _abi.lib()
+    for t in (train, test):
+        _abi.check(lib.mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), 3, _abi.ptr(rp), _abi.ptr(cp), U, I, _abi.stream_ptr()))
+    plan = DSGDPlan(U, I, world, ubp, ibp)
+    u0, u1 = plan.user_range(rank)
+    mine = (train[:, 0] >= u0) & (train[:, 0] < u1)
+    train_l = train[mine].contiguous()
+    tm = (test[:, 0] >= u0) & (test[:, 0] < u1)
+    test_l = test[tm].contiguous()
+    b = float(train[:, 2].double().mean().item())
+    del train, test, mine, tm
+    grids = []
+    for q in range(world):
+        i0, i1 = plan.item_range(q)
+        sel = (train_l[:, 1] >= i0) & (train_l[:, 1] < i1)
+        grids.append(Grid(train_l[sel].contiguous(), U, I, ubp, ibp, order=1))
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed)
+    P = torch.randn(U, k, device="cuda", generator=g) / k
+    Q = torch.randn(I, k, device="cuda", generator=g) / k
+    b_u = torch.zeros(U, device="cuda")
+    b_i = torch.zeros(I, device="cuda")
+
+    def compute(q):
+        _abi.check(lib.mfsgd_hip_epoch_f32(grids[q].handle, k, _abi.ptr(P), _abi.ptr(Q), _abi.ptr(b_u), _abi.ptr(b_i),
+                                           b, None, alpha, beta1, beta2, 0, 0, 1, 1, args.seed + q, args.wgs,
+                                           args.waves, None, _abi.stream_ptr()))
+
+    def errors():
+        gather_items(plan, rank, Q, b_i, dist)
+        acc = torch.zeros(4, dtype=torch.float64, device="cuda")
+        for j, s in enumerate((train_l, test_l)):
+            if s.shape[0]:
+                r = rmse_exact(s, None, None, P, Q, b_u, b_i, b)
+                acc[2 * j] = r * r * s.shape[0]
+                acc[2 * j + 1] = s.shape[0]
+        dist.all_reduce(acc)
+        return float((acc[0] / acc[1]).sqrt()), float((acc[2] / acc[3]).sqrt())
+
+    for _ in range(args.warmup):
+        ring_epoch(plan, rank, Q, b_i, compute, dist)
+    for gr in grids:
+        gr.status()
+    rm0 = errors()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ring_epoch(plan, rank, Q, b_i, compute, dist)
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    for gr in grids:
+        gr.status()
+    rm1 = errors()
+    if rank == 0:
+        value = args.steps * n_train_total / wall
+        Bk = bytes_per_update(k, "none")
+        out = {
+            "metric": "rating-updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shape {U}x{I}, {n_train_total} train ratings, k={k}, implicit=none, "
+                                   f"DSGD ring over {world} GPUs, grid {plan.Gr}x{plan.Gc}, balanced renumbering",
+                       "n_train": n_train_total, "k": k, "grid": [plan.Gr, plan.Gc], "prep_seconds": prep_s},
+            "roofline": {"bound": "hbm", "achieved": Bk * value / world / 1e9, "peak": hbm_peak / 1e9, "unit": "GB/s",
+                         "frac": Bk * value / world / hbm_peak, "traffic": None, "bytes_per_update": Bk,
+                         "kernel": "k_epoch_free", "note": "per GPU, whole sub-epoch incl. ring exchange"},
+            "rmse": {"train_before": rm0[0], "test_before": rm0[1], "train_after": rm1[0], "test_after": rm1[1]},
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
