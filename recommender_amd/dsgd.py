@@ -16,7 +16,7 @@ rule it implements is the same FPSGD invariant (RayBlockScheduler.py:50-62) one 
     one all-reduce of four numbers.
 
 The plan (who holds what when) is pure Python and runs anywhere; the compute step is a callable, so the
-CPU tests drive the same ring with the oracle's block kernel under gloo.
+CPU tests drive the same ring with a CPU block kernel of their own under gloo.
 """
 import time
 
