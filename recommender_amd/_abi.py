@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfsgd.so")
+# MFSGD_LIBRARY: another build of the same C-ABI (profiles/ uses an instrumented one); never a CPU stand-in
+LIB_PATH = os.environ.get("MFSGD_LIBRARY") or os.path.join(_HERE, "libmfsgd.so")
 _lib = None
 
 c_f32, c_f64, c_i32, c_i64, c_u64, c_vp = C.c_float, C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p

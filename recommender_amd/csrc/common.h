@@ -26,7 +26,7 @@ void mfsgd_set_error(const char *fmt, ...);
 
 #define MF_LAUNCH_CHECK() MF_HIP(hipGetLastError())
 
-// ---- wave64 sum.  f32: DPP butterfly inside each 16-lane row, then 4 readlanes; the tree is fixed,
+// ---- wave64 sum.  f32: DPP butterfly inside each 16-lane row, then two permlane swaps; the tree is fixed,
 // so the result is the same on every run and in every lane.
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -39,12 +39,12 @@ __device__ __forceinline__ float wave_sum(float v)
     v += __int_as_float(x);
     x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); // row_mirror
     v += __int_as_float(x);
-    const int iv = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
-    return (r0 + r1) + (r2 + r3);
+    // every lane of a 16-lane row now holds its row's sum; two gfx950 lane swaps fold the four rows without
+    // leaving the VALU (no readlane / SALU hop): rows (0,1),(2,3) first, then the two halves of the wave
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
 __device__ __forceinline__ double wave_sum(double v)

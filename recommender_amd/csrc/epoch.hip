@@ -66,6 +66,7 @@ struct GridView {
     const int32_t *col_order;
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
+    int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
 };
 
 struct SchedView {
@@ -126,7 +127,7 @@ __global__ void k_run_fill(const int32_t *__restrict__ flag, const int32_t *__re
                            int32_t *run_user)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) run_start[n_runs] = (int32_t)n;
+    if (t == 0) { run_start[n_runs] = (int32_t)n; run_start[n_runs + 1] = (int32_t)n; }
     if (t >= n || !flag[t]) return;
     run_start[excl[t]] = (int32_t)t;
     run_user[excl[t]] = user[t];
@@ -218,6 +219,26 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------ epoch kernel
+// -DMFSGD_PROF builds a separate measuring library (profiles/Makefile): per-wave time stamps around the
+// phases of a block, summed into 16 counters behind the column clocks.  The shipped library has none of it.
+#ifdef MFSGD_PROF
+#define PF_PARAM , unsigned long long *pf
+#define PF_PASS , pf
+#define PF_T(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#define PF_ADD(slot, from, to) pf[slot] += (to) - (from)
+#define PF_INC(slot, v) pf[slot] += (v)
+#define PF_PIN(x) asm volatile("" ::"v"(x))
+#else
+#define PF_PARAM
+#define PF_PASS
+#define PF_T(name)
+#define PF_ADD(slot, from, to)
+#define PF_INC(slot, v)
+#define PF_PIN(x)
+#endif
+enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_TAIL, PF_DRAIN, PF_BARRIER, PF_RUNS,
+       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_SLOTS = 16 };
+
 constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
 enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_SINK = 16 };
 
@@ -257,6 +278,15 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     return p;
 }
 
+__device__ __forceinline__ void untracked_store(float *p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void untracked_store(double *p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
 // Stage 1 of a run: which run, whose, and where its ratings are (wave-uniform words).
 struct RunIdx {
     int32_t j, u, t0, t1;
@@ -293,7 +323,10 @@ __device__ __forceinline__ void load_meta(const GridView &g, int32_t t, int32_t 
 
 // Issues the loads of a run's head; nothing here waits, so a caller can keep two runs in flight behind the
 // one it is walking and the HBM latency of the row and of the metadata hides behind that walk.
-template <typename T, int KC>
+// FAST (k a multiple of 64, no implicit term): no lane guard and no optional load, so the loop that calls this
+// is straight-line code and hipcc can count vmcnt exactly (with any conditional load in the pipeline it falls
+// back to waiting for the youngest loads, i.e. exposes a full HBM round trip per run).
+template <typename T, int KC, bool FAST>
 __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, const T *__restrict__ P,
                                          const T *__restrict__ b_u, const T *__restrict__ z, int k, int lane,
                                          RunHead<T, KC> &h)
@@ -307,7 +340,9 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     for (int c = 0; c < KC; ++c) {
         const int f = lane + 64 * c;
         h.p[c] = 0; h.zz[c] = 0;
-        if (f < k) {
+        if (FAST) {
+            h.p[c] = prow[f];
+        } else if (f < k) {
             h.p[c] = prow[f];
             if (z) h.zz[c] = z[(int64_t)h.u * k + f];
         }
@@ -317,13 +352,18 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     load_meta(g, h.t0, h.t1, lane, h.m_item, h.m_tick, h.m_val);
 }
 
-template <typename T, int KC, bool STAGE>
+template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
-                                         T *bis, int lane, int32_t *err)
+                                         T *bis, int lane, int32_t *err PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
+    PF_T(w0);
+    PF_PIN(h.m_item); PF_PIN(h.m_tick); PF_PIN(h.m_val); PF_PIN(h.p[0]); PF_PIN(h.p[KC - 1]); PF_PIN(h.bu);
+    PF_T(w1);
+    PF_ADD(PF_HEADWAIT, w0, w1);
+    PF_INC(PF_RUNS, 1);
     T p[KC], zz[KC], q[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) { p[c] = h.p[c]; zz[c] = h.zz[c]; }
@@ -338,30 +378,37 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         const int32_t il = ig - c_base;
         const int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
-        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                                &tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tk; ++spins) {
-            if (spins >= SPIN_TICKET_MAX) {
-                atomicOr(err, 1);
-                break;
-            }
-            if (spins > 8) __builtin_amdgcn_s_sleep(1);
-        }
-        // STAGE: ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in
-        // issue order, so ordering needs no wait at all - only the compiler must keep program order (a
-        // workgroup-scope fence over all address spaces would also drain vmcnt, i.e. stall the item's chain
-        // on this wave's prefetched HBM loads).  Otherwise Q is in global memory: full workgroup fences.
-        if (STAGE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         T bi;
         T *qrow = Q + (int64_t)ig * k;
+        PF_T(r0);
         if (STAGE) {
+            // Ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in issue
+            // order.  So each poll issues the ticket read AND the row reads back to back: if the ticket read
+            // returns this rating's ticket, the row reads behind it already saw the predecessor's row (it
+            // wrote the row before the ticket) - one LDS round trip per hand-off instead of two, and no
+            // s_waitcnt on anything but LDS (a workgroup-scope fence over all address spaces would also
+            // drain vmcnt, i.e. stall the item's chain on this wave's prefetched HBM loads).
+            for (int spins = 0;; ++spins) {
+                const int32_t seen = __hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order only
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const int f = lane + 64 * c;
-                q[c] = f < k ? qs[(size_t)il * k + f] : (T)0;
+                for (int c = 0; c < KC; ++c) {
+                    const int f = lane + 64 * c;
+                    q[c] = f < k ? qs[(size_t)il * k + f] : (T)0;
+                }
+                bi = bis[il];
+                if (__builtin_amdgcn_readfirstlane(seen) == tk) break;
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                if (spins > 8) __builtin_amdgcn_s_sleep(1);
+                PF_INC(PF_SPINS, 1);
             }
-            bi = bis[il];
         } else {
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                    &tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tk; ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                if (spins > 8) __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // Q is in global memory: full fence
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 const int f = lane + 64 * c;
@@ -369,19 +416,25 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             }
             bi = __hip_atomic_load(&b_i[ig], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        // the item's chain is serial across waves: only what the NEXT holder needs (the new row and b_i)
+        // is computed before the ticket is passed on; b_u and the p registers are settled afterwards
+        PF_PIN(q[0]); PF_PIN(q[KC - 1]); PF_PIN(bi);
+        PF_T(r1);
+        PF_ADD(PF_POLL, r0, r1);
+        PF_INC(PF_RATINGS, 1);
+        const T rest = r - b - bu;
         T part = 0;
 #pragma unroll
         for (int c = 0; c < KC; ++c) part += q[c] * (p[c] + zz[c]);
-        const T e = r - (wave_sum(part) + bu + bi + b);
-        bu += alpha * (e - beta1 * bu);
-        bi += alpha * (e - beta1 * bi);
+        const T e = rest - bi - wave_sum(part);
+        T pn[KC];
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            const T pn = p[c] + alpha * (e * q[c] - beta2 * p[c]);
-            const T pu = variant == 0 ? pn : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
+            pn[c] = p[c] + alpha * (e * q[c] - beta2 * p[c]);
+            const T pu = variant == 0 ? pn[c] : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
             q[c] = q[c] + alpha * (e * (pu + zz[c]) - beta2 * q[c]);
-            p[c] = pn;
         }
+        bi += alpha * (e - beta1 * bi);
         if (STAGE) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -389,6 +442,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                 if (f < k) qs[(size_t)il * k + f] = q[c];
             }
             *sink_ptr(&bis[il], ctl, lane) = bi;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -396,27 +450,47 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                 if (f < k) qrow[f] = q[c];
             }
             __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
-        if (STAGE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(sink_ptr(&tick_done[il], ctl, lane), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+        bu += alpha * (e - beta1 * bu);
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const int f = lane + 64 * c;
-        if (f < k) prow[f] = p[c];
+        for (int c = 0; c < KC; ++c) p[c] = pn[c];
+        PF_PIN(p[0]); PF_PIN(p[KC - 1]);
+        PF_T(r2);
+        PF_ADD(PF_UPDATE, r1, r2);
     }
-    __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
+    PF_T(w2);
+    if (FAST) {
+        // Stores the compiler does not see (untracked_store): with a tracked store pending, hipcc's wait
+        // insertion treats vmcnt as out of order on gfx9-class targets and turns every later wait for a
+        // prefetched load into vmcnt(0) - the whole pipeline would drain once per run.  Untracked stores only
+        // make its counted waits a little more conservative (the real queue is longer than it thinks),
+        // never less.  process_block drains vmcnt(0) by hand before the block's closing barrier.
+#pragma unroll
+        for (int c = 0; c < KC; ++c) untracked_store(prow + lane + 64 * c, p[c]);
+        untracked_store(&b_u[u], bu);   // all lanes, same word
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int f = lane + 64 * c;
+            if (f < k) prow[f] = p[c];
+        }
+        __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
+    }
+    PF_T(w3);
+    PF_ADD(PF_TAIL, w2, w3);
 }
 
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
-template <typename T, int KC, bool STAGE>
+template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis, int32_t *err)
+                                              int *tick_done, T *qs, T *bis, int32_t *err PF_PARAM)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    PF_T(b0);
     const int32_t bid = r * g.Gc + c;
     const int32_t run_lo = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid]);
     const int32_t run_hi = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid + 1]);
@@ -433,27 +507,41 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         // issued.  Runs are handed out in stored order and a wave finishes a run before it walks the next
         // one it claimed, so the earliest unfinished rating is always being walked: ticket waits cannot
         // deadlock however far ahead the claims run.
+        // Claims past the end of the block are turned into the grid's sentinel run (an empty run after the
+        // last real one): its loads are issued like any other and never used, so nothing in the loop is
+        // conditional except the walk itself.
         auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
+        auto real = [&](int32_t jj) { return jj < run_hi ? jj : g.sentinel_run; };
+        // Pipeline per wave: walking run j, head loads (row, bias, rating metadata) of run j+1 in flight,
+        // index words of runs j+2 and j+3 in flight.  The index words are consumed a full iteration after
+        // they were issued, so the counted vmcnt that guards them leaves the younger loads (and the
+        // untracked stores) of the last iteration in flight.
         RunHead<T, KC> cur, nxt;
-        RunIdx xn{}, xf{};
+        RunIdx xn, xf, xg;
         int32_t j = claim();
-        if (j < run_hi) {
-            RunIdx x0;
-            run_index(g, j, x0);
-            load_run<T, KC>(g, x0, P, b_u, z, k, lane, cur);
-        }
-        int32_t jn = j < run_hi ? claim() : run_hi;
-        if (jn < run_hi) run_index(g, jn, xn);
+        run_index(g, real(j), xn);
+        load_run<T, KC, FAST>(g, xn, P, b_u, z, k, lane, cur);
+        int32_t jn = claim();
+        run_index(g, real(jn), xn);
+        int32_t jf = claim();
+        run_index(g, real(jf), xf);
+        PF_T(b1);
+        PF_ADD(PF_PROLOGUE, b0, b1);
         while (j < run_hi) {
-            const int32_t jf = jn < run_hi ? claim() : run_hi;
-            if (jf < run_hi) run_index(g, jf, xf);
-            if (jn < run_hi) load_run<T, KC>(g, xn, P, b_u, z, k, lane, nxt);
-            walk_run<T, KC, STAGE>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl, tick_done,
-                                   qs, bis, lane, err);
+            PF_T(i0);
+            load_run<T, KC, FAST>(g, xn, P, b_u, z, k, lane, nxt);
+            const int32_t jg = claim();
+            run_index(g, real(jg), xg);
+            PF_T(i1);
+            PF_ADD(PF_ISSUE, i0, i1);
+            walk_run<T, KC, STAGE, FAST>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                         tick_done, qs, bis, lane, err PF_PASS);
             cur = nxt;
             xn = xf;
+            xf = xg;
             j = jn;
             jn = jf;
+            jf = jg;
         }
     } else {
         // a user may own several runs of this block: all of them go to one wave, in stored order
@@ -462,14 +550,20 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             RunHead<T, KC> cur;
             RunIdx x;
             run_index(g, j, x);
-            load_run<T, KC>(g, x, P, b_u, z, k, lane, cur);
-            walk_run<T, KC, STAGE>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl, tick_done,
-                                   qs, bis, lane, err);
+            load_run<T, KC, false>(g, x, P, b_u, z, k, lane, cur);
+            walk_run<T, KC, STAGE, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                          tick_done, qs, bis, lane, err PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
+    PF_T(b2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PF_T(b3);
     __syncthreads();
+    PF_T(b4);
+    PF_ADD(PF_DRAIN, b2, b3);
+    PF_ADD(PF_BARRIER, b3, b4);
+    PF_ADD(PF_BLOCK, b0, b4);
 }
 
 template <typename T, bool STAGE>
@@ -517,12 +611,16 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
     }
     if (g.blk_run_ptr[r * g.Gc + c] == g.blk_run_ptr[r * g.Gc + c + 1]) return;
     stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
-    process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs, bis, s.err);
+#ifdef MFSGD_PROF
+    unsigned long long pf[PF_SLOTS] = {};
+#endif
+    process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
+                                       bis, s.err PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
 // schedule 1: persistent workgroups, column tenure + row locks
-template <typename T, int KC, bool STAGE>
+template <typename T, int KC, bool STAGE, bool FAST>
 __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
@@ -535,6 +633,10 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
     // selects wave 0 is scalar, and nothing inside is predicated per lane (sink_ptr).
     const bool sched_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+#ifdef MFSGD_PROF
+    unsigned long long pf[PF_SLOTS] = {};
+    PF_T(k0);
+#endif
     for (;;) {
         if (sched_wave) {
             const int32_t ci = __builtin_amdgcn_readlane(
@@ -609,8 +711,8 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
             const int32_t r = __builtin_amdgcn_readfirstlane(ctl[CTL_ROW]);
             if (r < 0) break;
             if (!(s.dbg & 4))
-                process_block<T, KC, STAGE>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl,
-                                            tick_done, qs, bis, s.err);
+                process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
+                                                  ctl, tick_done, qs, bis, s.err PF_PASS);
             if (sched_wave) {
                 // release: every wave drained its stores before the barrier that ended process_block
                 if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -621,6 +723,14 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
+#ifdef MFSGD_PROF
+    PF_T(k1);
+    pf[PF_TENURE] = k1 - k0;
+    pf[PF_SCHED] = pf[PF_TENURE] - pf[PF_BLOCK];
+    unsigned long long *out = (unsigned long long *)(s.col_clock + 2 * g.Gc);
+    for (int i = 0; i < PF_SLOTS; ++i)
+        atomicAdd((unsigned long long *)sink_ptr(out + i, ctl, lane), pf[i]);
+#endif
 }
 
 template <typename T, int KC, bool STAGE>
@@ -648,7 +758,8 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         }
         return MFSGD_OK;
     }
-    auto kern = k_epoch_free<T, KC, STAGE>;
+    const bool fast = k == 64 * KC && z == nullptr;
+    auto kern = fast ? k_epoch_free<T, KC, STAGE, true> : k_epoch_free<T, KC, STAGE, false>;
     const char *dbg_env = getenv("MFSGD_DEBUG_FLAGS");
     const int32_t dbg = dbg_env ? atoi(dbg_env) : 0;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
@@ -686,7 +797,8 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     const mfsgd_grid_info &in = G->info;
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
-                in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items};
+                in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
+                (int32_t)in.n_runs};
     const bool dynamic = schedule == 1;
     const size_t cap = (size_t)160 * 1024;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
@@ -764,6 +876,17 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
     std::vector<long long> clk(2 * Gc);
     MF_HIP(hipMemcpyAsync(clk.data(), g->col_clock, sizeof(long long) * 2 * Gc, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
+#ifdef MFSGD_PROF
+    {
+        static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
+                                              "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure"};
+        unsigned long long pf[PF_SLOTS];
+        MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
+        MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
+        for (int i = 0; i < PF_SLOTS; ++i)
+            if (names[i]) fprintf(stderr, "prof %-13s %14llu  (%.1f%% of tenure)\n", names[i], pf[i], 100.0 * pf[i] / (double)pf[PF_TENURE]);
+    }
+#endif
     for (size_t c = 0; c < Gc; ++c) {
         h_nnz_start_end[3 * c] = g->col_nnz.empty() ? 0 : g->col_nnz[c];
         h_nnz_start_end[3 * c + 1] = clk[2 * c];
@@ -803,14 +926,15 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
     MF_HIP(dalloc(&G->counters, 16));
-    MF_HIP(dalloc(&G->col_clock, (size_t)Gc * 2));
-    MF_HIP(hipMemsetAsync(G->col_clock, 0, sizeof(long long) * 2 * (size_t)Gc, st));
+    MF_HIP(dalloc(&G->col_clock, (size_t)Gc * 2 + PF_SLOTS));
+    MF_HIP(hipMemsetAsync(G->col_clock, 0, sizeof(long long) * (2 * (size_t)Gc + PF_SLOTS), st));
     MF_HIP(hipMemsetAsync(G->counters, 0, 64, st));
     std::vector<int32_t> h_blk((size_t)nb + 1, 0);
     if (n == 0) {
         MF_HIP(hipMemsetAsync(G->blk_run_ptr, 0, sizeof(int32_t) * (size_t)(nb + 1), st));
-        MF_HIP(dalloc(&G->run_start, 1)); MF_HIP(dalloc(&G->run_user, 1));
-        MF_HIP(hipMemsetAsync(G->run_start, 0, 4, st));
+        MF_HIP(dalloc(&G->run_start, 2)); MF_HIP(dalloc(&G->run_user, 1));
+        MF_HIP(hipMemsetAsync(G->run_start, 0, 8, st));
+        MF_HIP(hipMemsetAsync(G->run_user, 0, 4, st));
         MF_HIP(hipStreamSynchronize(st));
         guard.g = nullptr; *out = G;
         return MFSGD_OK;
@@ -874,7 +998,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(hipStreamSynchronize(st));
     const int32_t n_runs = last_excl + last_flag;
     G->info.n_runs = n_runs;
-    MF_HIP(dalloc(&G->run_start, (size_t)n_runs + 1)); MF_HIP(dalloc(&G->run_user, (size_t)n_runs));
+    MF_HIP(dalloc(&G->run_start, (size_t)n_runs + 2)); MF_HIP(dalloc(&G->run_user, (size_t)n_runs + 1));
+    MF_HIP(hipMemsetAsync(G->run_user + n_runs, 0, 4, st));   // the sentinel run belongs to user 0 and is empty
     hipLaunchKernelGGL(k_run_fill, dim3(nblk(n)), dim3(256), 0, st, flag.as<int32_t>(), excl.as<int32_t>(),
                        user.as<int32_t>(), n, n_runs, G->run_start, G->run_user);
     MF_LAUNCH_CHECK();
