@@ -110,6 +110,8 @@ typedef struct {
     int32_t order;        /* 0 = reference order inside a block, 1 = user-sorted inside a block */
     int32_t user_unique;  /* 1 if no user has two runs in one block */
     int64_t max_block, max_col_nnz, max_row_nnz;
+    int32_t n_served;     /* item stripes whose most rated item gets a server wave in the free-block kernel */
+    int32_t reserved;
 } mfsgd_grid_info;
 
 /* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);

@@ -21,7 +21,8 @@ class GridInfo(C.Structure):
     _fields_ = [("n", c_i64), ("n_runs", c_i64), ("n_users", c_i64), ("n_items", c_i64),
                 ("Gr", c_i32), ("Gc", c_i32), ("ubp", c_i32), ("ibp", c_i32),
                 ("order", c_i32), ("user_unique", c_i32),
-                ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64)]
+                ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64),
+                ("n_served", c_i32), ("reserved", c_i32)]
 
 
 def _sig_sgd(ct):

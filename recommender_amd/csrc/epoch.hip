@@ -50,6 +50,8 @@ struct mfsgd_grid {
     int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
     float *val = nullptr;
     int32_t *col_order = nullptr;  // item stripes, heaviest first
+    int32_t *col_hot = nullptr;      // [Gc] the stripe's most rated item (global id) if it is worth a server wave, else -1
+    int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings of that item in the block
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -67,6 +69,7 @@ struct GridView {
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
+    const int32_t *col_hot, *blk_hot_cnt;
 };
 
 struct SchedView {
@@ -80,6 +83,9 @@ struct SchedView {
 
 constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
 constexpr int SPIN_LOCK_SWEEPS = 1 << 20;
+#ifndef TICKET_NAP
+#define TICKET_NAP 3   // s_sleep units (64 clocks) a waiter sleeps per hand-off in front of it
+#endif
 
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -194,6 +200,36 @@ inline int bits_for(uint64_t maxkey)
     return b;
 }
 
+__global__ void k_item_deg(const int32_t *__restrict__ item, int64_t n, int32_t *deg)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(&deg[item[t]], 1);
+}
+
+// The most rated item of a stripe gets a server wave (see HotRing) when it carries at least 1/16 of the stripe's
+// ratings, i.e. more than one wave's fair share: below that its chain is not what bounds the stripe.
+__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot)
+{
+    const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Gc) return;
+    int64_t total = 0;
+    int32_t best = -1, best_deg = 0;
+    for (int64_t i = (int64_t)c * ibp; i < (int64_t)(c + 1) * ibp && i < n_items; ++i) {
+        total += deg[i];
+        if (deg[i] > best_deg) { best_deg = deg[i]; best = (int32_t)i; }
+    }
+    col_hot[c] = (best_deg >= 256 && (int64_t)best_deg * 16 >= total) ? best : -1;
+}
+
+__global__ void k_blk_hot(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ item, int64_t n, int32_t Gc,
+                          const int32_t *__restrict__ col_hot, int32_t *blk_hot_cnt)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t bid = bkey[t];
+    if (item[t] == col_hot[bid % (uint32_t)Gc]) atomicAdd(&blk_hot_cnt[bid], 1);
+}
+
 template <typename K, typename V>
 int sort_pairs_t(K *k_in, K *k_out, V *v_in, V *v_out, int64_t n, int end_bit, hipStream_t st)
 {
@@ -237,7 +273,7 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 #define PF_PIN(x)
 #endif
 enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_TAIL, PF_DRAIN, PF_BARRIER, PF_RUNS,
-       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_SLOTS = 16 };
+       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 24 };
 
 constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
 enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_SINK = 16 };
@@ -260,7 +296,23 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    size_t ctl, tick, rowdone, qs, bis, total;
+    size_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, total;
+};
+
+// Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
+// the row its predecessor wrote.  Through the LDS ticket that hand-off costs a poll, a row read, the update and
+// a row write per link (~0.3 us), and the most rated items have 10^5 links per epoch.  So the last wave of the
+// workgroup keeps that item's row and bias in REGISTERS for the whole block and serves it: a worker that meets
+// the item posts its user row, bias and rating in ring slot (ticket mod HOT_R) and sleeps; the server takes the
+// slots in ticket order (the next request is prefetched while the current one is computed, so a link costs
+// the arithmetic only), writes the updated user row and bias back into the slot, and the worker picks them up.
+// Slot state word: 3g = free for generation g = ticket / HOT_R, 3g+1 = request posted, 3g+2 = answered.
+constexpr int HOT_R = 16;   // >= waves per workgroup: a worker has at most one request posted
+template <typename T> struct HotRing {
+    int *st;       // [HOT_R]
+    T *s;          // [HOT_R][2]  {b_u, rating}
+    T *p;          // [HOT_R][k]
+    int32_t item;  // global id of the served item, -1: nobody is served in this stripe
 };
 
 template <typename T>
@@ -274,6 +326,9 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.rowdone = o; o = up(o + (dynamic ? (size_t)Gr : 0));
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
+    p.ring_st = o; o = up(o + (stage ? (size_t)HOT_R * 4 : 0));
+    p.ring_s = o; o = up(o + (stage ? (size_t)HOT_R * 2 * sizeof(T) : 0));
+    p.ring_p = o; o = up(o + (stage ? (size_t)HOT_R * k * sizeof(T) : 0));
     p.total = o;
     return p;
 }
@@ -352,11 +407,31 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     load_meta(g, h.t0, h.t1, lane, h.m_item, h.m_tick, h.m_val);
 }
 
-template <typename T, int KC, bool STAGE, bool FAST>
+// One rating (numba_methods.py:17-22 without the implicit write-back): error, new user row `pn`, new item row
+// in place, new item bias in place.  The caller settles b_u (it needs `e` only).
+template <typename T, int KC>
+__device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q)[KC], T &bi, T rest, T alpha, T beta1,
+                                      T beta2, int variant, T (&pn)[KC])
+{
+    T part = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) part += q[c] * (p[c] + zz[c]);
+    const T e = rest - bi - wave_sum(part);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        pn[c] = p[c] + alpha * (e * q[c] - beta2 * p[c]);
+        const T pu = variant == 0 ? pn[c] : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
+        q[c] = q[c] + alpha * (e * (pu + zz[c]) - beta2 * q[c]);
+    }
+    bi += alpha * (e - beta1 * bi);
+    return e;
+}
+
+template <typename T, int KC, bool STAGE, bool FAST, bool HOT>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
-                                         T *bis, int lane, int32_t *err PF_PARAM)
+                                         T *bis, int lane, int32_t *err, const HotRing<T> &hot PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
     PF_T(w0);
@@ -378,9 +453,43 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         const int32_t il = ig - c_base;
         const int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
+        if (HOT && ig == hot.item) {
+            // the stripe's served item: hand the user row to the server wave and take the answer (HotRing)
+            const int32_t hs = tk & (HOT_R - 1), gen3 = 3 * (tk / HOT_R);
+            int *stw = hot.st + hs;
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                    stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != gen3; ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int c = 0; c < KC; ++c) hot.p[(size_t)hs * k + lane + 64 * c] = p[c];
+            *sink_ptr(&hot.s[2 * hs], ctl, lane) = bu;
+            *sink_ptr(&hot.s[2 * hs + 1], ctl, lane) = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS keeps a wave's stores in order
+            __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int spins = 0;; ++spins) {
+                const int32_t seen = __hip_atomic_load(stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < KC; ++c) p[c] = hot.p[(size_t)hs * k + lane + 64 * c];
+                bu = hot.s[2 * hs];
+                if (__builtin_amdgcn_readfirstlane(seen) == gen3 + 2) break;
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PF_INC(PF_RATINGS, 1);
+            continue;
+        }
         T bi;
         T *qrow = Q + (int64_t)ig * k;
         PF_T(r0);
+#ifdef MFSGD_PROF
+        int32_t first_ahead = 0;
+#endif
         if (STAGE) {
             // Ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in issue
             // order.  So each poll issues the ticket read AND the row reads back to back: if the ticket read
@@ -394,14 +503,32 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #pragma unroll
                 for (int c = 0; c < KC; ++c) {
                     const int f = lane + 64 * c;
-                    q[c] = f < k ? qs[(size_t)il * k + f] : (T)0;
+                    q[c] = (FAST || f < k) ? qs[(size_t)il * k + f] : (T)0;
                 }
                 bi = bis[il];
-                if (__builtin_amdgcn_readfirstlane(seen) == tk) break;
+                int32_t ahead = tk - __builtin_amdgcn_readfirstlane(seen);
+#ifdef MFSGD_PROF
+                if (spins == 0) { first_ahead = ahead; }
+#endif
+                if (ahead == 0) break;
+#ifdef MFSGD_NOWAIT   // timing experiment (make nowait): ignore the item order - results are wrong on purpose
+                break;
+#endif
                 if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                if (spins > 8) __builtin_amdgcn_s_sleep(1);
                 PF_INC(PF_SPINS, 1);
+                // `ahead` ratings of this item still have to pass.  Only the immediate successor polls at full
+                // rate (row reads included); everybody further back sleeps through the hand-offs in front of it
+                // and looks at the ticket word alone, so waiting waves take neither issue slots nor LDS
+                // bandwidth from the wave that is on the item's critical path.
+                while (ahead > 1) {
+                    for (int32_t a = ahead > 9 ? 8 : ahead - 1; a > 0; --a) __builtin_amdgcn_s_sleep(TICKET_NAP);
+                    ahead = tk - __builtin_amdgcn_readfirstlane(
+                                     __hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (++spins >= SPIN_TICKET_MAX) break;
+                    PF_INC(PF_SPINS, 1);
+                }
             }
+            __builtin_amdgcn_s_setprio(2);   // holder of an item's ticket: the other waves of the SIMD are waiting on it
         } else {
             for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                     &tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != tk; ++spins) {
@@ -421,25 +548,19 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         PF_PIN(q[0]); PF_PIN(q[KC - 1]); PF_PIN(bi);
         PF_T(r1);
         PF_ADD(PF_POLL, r0, r1);
+#ifdef MFSGD_PROF
+        if (first_ahead == 0) { pf[PF_POLL0] += r1 - r0; pf[PF_N0] += 1; }
+        else if (first_ahead == 1) { pf[PF_POLL1] += r1 - r0; pf[PF_N1] += 1; }
+        pf[PF_AHEAD] += first_ahead;
+#endif
         PF_INC(PF_RATINGS, 1);
-        const T rest = r - b - bu;
-        T part = 0;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) part += q[c] * (p[c] + zz[c]);
-        const T e = rest - bi - wave_sum(part);
         T pn[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            pn[c] = p[c] + alpha * (e * q[c] - beta2 * p[c]);
-            const T pu = variant == 0 ? pn[c] : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
-            q[c] = q[c] + alpha * (e * (pu + zz[c]) - beta2 * q[c]);
-        }
-        bi += alpha * (e - beta1 * bi);
+        const T e = sgd_step<T, KC>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 const int f = lane + 64 * c;
-                if (f < k) qs[(size_t)il * k + f] = q[c];
+                if (FAST || f < k) qs[(size_t)il * k + f] = q[c];
             }
             *sink_ptr(&bis[il], ctl, lane) = bi;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -453,6 +574,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
         __hip_atomic_store(sink_ptr(&tick_done[il], ctl, lane), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (STAGE) __builtin_amdgcn_s_setprio(0);
         bu += alpha * (e - beta1 * bu);
 #pragma unroll
         for (int c = 0; c < KC; ++c) p[c] = pn[c];
@@ -487,8 +609,9 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis, int32_t *err PF_PARAM)
+                                              int *tick_done, T *qs, T *bis, int32_t *err, HotRing<T> hot PF_PARAM)
 {
+    constexpr bool HOT = STAGE && FAST;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
     const int32_t bid = r * g.Gc + c;
@@ -499,7 +622,58 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
     ctl[CTL_RUN] = run_lo;  // every thread, same value
+    int32_t n_hot = 0;
+    if (HOT) {
+        if (!g.user_unique || nw < 4) hot.item = -1;   // a server needs workers beside it
+        if (hot.item >= 0) n_hot = __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[bid]);
+        if (tid < HOT_R) hot.st[tid] = 0;
+    }
     __syncthreads();
+    if (HOT && n_hot > 0 && __builtin_amdgcn_readfirstlane(wave) == nw - 1) {
+        // ---- server of the stripe's most rated item (HotRing): row and bias in registers for the whole block
+        const int32_t hl = hot.item - c_base;
+        T q[KC], zz[KC], rp[KC], bi, rbu, rr;
+        int32_t seen;
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
+        bi = bis[hl];
+        auto fetch = [&](int32_t hs) {   // state word first: LDS serves a wave's reads in order
+            seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
+            rbu = hot.s[2 * hs];
+            rr = hot.s[2 * hs + 1];
+        };
+        __builtin_amdgcn_s_setprio(3);
+        fetch(0);
+        for (int32_t t = 0; t < n_hot; ++t) {
+            const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                if (spins > 4) __builtin_amdgcn_s_sleep(1);
+                fetch(hs);
+            }
+            T cp[KC], pn[KC];
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
+            T cbu = rbu;
+            const T rest = rr - b - cbu;
+            fetch((t + 1) & (HOT_R - 1));   // the next request, if it is already there, arrives behind the arithmetic
+            const T e = sgd_step<T, KC>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
+            cbu += alpha * (e - beta1 * cbu);
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
+            *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
+        *sink_ptr(&bis[hl], ctl, lane) = bi;
+        // nobody reads the item's row before the closing barrier: workers never touch it, later blocks come after
+    }
     if (g.user_unique) {
         // branch-free dequeue on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around
         // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
@@ -534,8 +708,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             run_index(g, real(jg), xg);
             PF_T(i1);
             PF_ADD(PF_ISSUE, i0, i1);
-            walk_run<T, KC, STAGE, FAST>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                         tick_done, qs, bis, lane, err PF_PASS);
+            walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                              tick_done, qs, bis, lane, err, hot PF_PASS);
             cur = nxt;
             xn = xf;
             xf = xg;
@@ -551,8 +725,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             RunIdx x;
             run_index(g, j, x);
             load_run<T, KC, false>(g, x, P, b_u, z, k, lane, cur);
-            walk_run<T, KC, STAGE, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                          tick_done, qs, bis, lane, err PF_PASS);
+            walk_run<T, KC, STAGE, false, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                                 tick_done, qs, bis, lane, err, hot PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -614,8 +788,9 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
 #endif
+    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), -1};
     process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
-                                       bis, s.err PF_PASS);
+                                       bis, s.err, hot PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -663,6 +838,8 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
         stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
+        const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
+                             __builtin_amdgcn_readfirstlane(g.col_hot[c])};
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -712,7 +889,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
             if (r < 0) break;
             if (!(s.dbg & 4))
                 process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
-                                                  ctl, tick_done, qs, bis, s.err PF_PASS);
+                                                  ctl, tick_done, qs, bis, s.err, hot PF_PASS);
             if (sched_wave) {
                 // release: every wave drained its stores before the barrier that ended process_block
                 if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -798,7 +975,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs};
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt};
     const bool dynamic = schedule == 1;
     const size_t cap = (size_t)160 * 1024;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
@@ -831,7 +1008,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters, g->col_clock};
+                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -879,7 +1056,8 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
 #ifdef MFSGD_PROF
     {
         static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
-                                              "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure"};
+                                              "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure", "poll|ahead=0", "n|ahead=0",
+                                              "sum ahead", "poll|ahead=1", "n|ahead=1"};
         unsigned long long pf[PF_SLOTS];
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
@@ -924,6 +1102,9 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->blk_run_ptr, (size_t)nb + 1));
     MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
+    MF_HIP(dalloc(&G->col_hot, (size_t)Gc)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
+    MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc, st));
+    MF_HIP(hipMemsetAsync(G->blk_hot_cnt, 0, sizeof(int32_t) * (size_t)nb, st));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
     MF_HIP(dalloc(&G->counters, 16));
     MF_HIP(dalloc(&G->col_clock, (size_t)Gc * 2 + PF_SLOTS));
@@ -1050,6 +1231,24 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         MF_HIP(hipMemcpyAsync(&hd, dup.p, 4, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
         G->info.user_unique = hd ? 0 : 1;
+    }
+    // 5b. the item of every stripe whose chain gets a server wave, and how often it occurs in each block
+    if (G->info.user_unique) {
+        DevBuf deg;
+        MF_HIP(deg.alloc((size_t)n_items * 4));
+        MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
+        hipLaunchKernelGGL(k_item_deg, dim3(nblk(n)), dim3(256), 0, st, G->item, n, deg.as<int32_t>());
+        MF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
+                           G->col_hot);
+        MF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_blk_hot, dim3(nblk(n)), dim3(256), 0, st, bkey, G->item, n, (int32_t)Gc, G->col_hot,
+                           G->blk_hot_cnt);
+        MF_LAUNCH_CHECK();
+        std::vector<int32_t> h_hot((size_t)Gc);
+        MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        for (int32_t v : h_hot) G->info.n_served += v >= 0;
     }
     MF_HIP(hipStreamSynchronize(st));
     // 6. stripe weights (host, Gr*Gc words): heaviest item stripe first

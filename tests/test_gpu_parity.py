@@ -230,9 +230,12 @@ def test_deterministic_mode_matches_reference(ra, tag, mode, dtype, tol):
 
 
 # ------------------------------------------------------------------ free-block schedule == some serial order
-def _synthetic(rng, U, I, n):
+def _synthetic(rng, U, I, n, lead=False):
     u = (U * rng.random(n) ** 1.7).astype(np.int64)
     i = (I * rng.random(n) ** 2.2).astype(np.int64)
+    if lead:   # half of the users also rate the last item: its (sparse) stripe is led by one item -> server wave
+        uu = np.flatnonzero(rng.random(U) < 0.5)
+        u, i = np.concatenate([u, uu]), np.concatenate([i, np.full(len(uu), I - 1)])
     key = np.unique(u * I + i)
     u, i = key // I, key % I
     r = rng.integers(1, 6, size=len(key))
@@ -253,13 +256,14 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
     from recommender_amd import _abi
     from recommender_amd.SGDRecommender import Grid
     rng = np.random.default_rng(k + n)
-    s = _synthetic(rng, U, I, n)
+    s = _synthetic(rng, U, I, n, lead=k in (64, 128))
     Gr, Gc = grid
     ubp, ibp = -(-U // Gr), -(-I // Gc)
     Gr, Gc = -(-U // ubp), -(-I // ibp)
     d_s = torch.from_numpy(s).cuda()
     gr = Grid(d_s, U, I, ubp, ibp, order=1)
     assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
+    assert gr.info.n_served > 0 or k not in (64, 128)   # the server-wave path runs in the k=64,128 "none" cases
     P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
     Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
     y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
