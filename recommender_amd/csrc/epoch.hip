@@ -52,6 +52,8 @@ struct mfsgd_grid {
     int32_t *col_order = nullptr;  // item stripes, heaviest first
     int32_t *col_hot = nullptr;      // [Gc] the stripe's most rated item (global id) if it is worth a server wave, else -1
     int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings of that item in the block
+    int32_t *col_hot_deg = nullptr;  // [Gc] ratings of that item in the whole stripe (0 when col_hot < 0)
+    int32_t max_block_runs = 0;
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -69,7 +71,7 @@ struct GridView {
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
-    const int32_t *col_hot, *blk_hot_cnt;
+    const int32_t *col_hot, *blk_hot_cnt, *col_hot_deg;
 };
 
 struct SchedView {
@@ -208,7 +210,8 @@ __global__ void k_item_deg(const int32_t *__restrict__ item, int64_t n, int32_t 
 
 // The most rated item of a stripe gets a server wave (see HotRing) when it carries at least 1/16 of the stripe's
 // ratings, i.e. more than one wave's fair share: below that its chain is not what bounds the stripe.
-__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot)
+__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot,
+                          int32_t *col_hot_deg)
 {
     const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Gc) return;
@@ -218,7 +221,9 @@ __global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int3
         total += deg[i];
         if (deg[i] > best_deg) { best_deg = deg[i]; best = (int32_t)i; }
     }
-    col_hot[c] = (best_deg >= 256 && (int64_t)best_deg * 16 >= total) ? best : -1;
+    const bool serve = best_deg >= 256 && (int64_t)best_deg * 16 >= total;
+    col_hot[c] = serve ? best : -1;
+    col_hot_deg[c] = serve ? best_deg : 0;
 }
 
 __global__ void k_blk_hot(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ item, int64_t n, int32_t Gc,
@@ -273,7 +278,7 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 #define PF_PIN(x)
 #endif
 enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_TAIL, PF_DRAIN, PF_BARRIER, PF_RUNS,
-       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 24 };
+       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 32 };
 
 constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
 enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_SINK = 16 };
@@ -296,8 +301,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    size_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, total;
+    size_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, rt_u, rt_t, total;
 };
+constexpr int RT_CAP = 512;   // runs per block the LDS run table takes
 
 // Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
 // the row its predecessor wrote.  Through the LDS ticket that hand-off costs a poll, a row read, the update and
@@ -324,11 +330,14 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.ctl = o; o = up(o + CTL_WORDS * 4);
     p.tick = o; o = up(o + (size_t)ibp * 4);
     p.rowdone = o; o = up(o + (dynamic ? (size_t)Gr : 0));
+    p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 12 : 0));
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
     p.ring_st = o; o = up(o + (stage ? (size_t)HOT_R * 4 : 0));
     p.ring_s = o; o = up(o + (stage ? (size_t)HOT_R * 2 * sizeof(T) : 0));
     p.ring_p = o; o = up(o + (stage ? (size_t)HOT_R * k * sizeof(T) : 0));
+    p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
+    p.rt_t = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.total = o;
     return p;
 }
@@ -350,6 +359,7 @@ struct RunIdx {
 // Stage 2: the user's row (+ implicit term, bias) and the first 64 ratings of the run, one rating per lane.
 template <typename T, int KC> struct RunHead {
     int32_t u, t0, t1;
+    int32_t real, seq, es;   // streaming kernel: claimed run or hole, block sequence number, queue slot
     T p[KC], zz[KC], bu;
     int32_t m_item, m_tick;
     float m_val;
@@ -427,11 +437,14 @@ __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q
     return e;
 }
 
-template <typename T, int KC, bool STAGE, bool FAST, bool HOT>
+// CUM (streaming kernel): tickets count from the start of the column tenure, not of the block; `tbase[il]` is
+// the number of ratings of stripe item il in the blocks of this tenure that precede the run's block.
+template <typename T, int KC, bool STAGE, bool FAST, bool HOT, bool CUM = false>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
-                                         T *bis, int lane, int32_t *err, const HotRing<T> &hot PF_PARAM)
+                                         T *bis, int lane, int32_t *err, const HotRing<T> &hot, const int *tbase,
+                                         int *fl_word, int32_t fl_cnt PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
     PF_T(w0);
@@ -451,18 +464,22 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         if (slot == 0 && t != t0) load_meta(g, t, t1, lane, m_item, m_tick, m_val);  // runs longer than 64
         const int32_t ig = __builtin_amdgcn_readlane(m_item, slot);
         const int32_t il = ig - c_base;
-        const int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
+        int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
         if (HOT && ig == hot.item) {
             // the stripe's served item: hand the user row to the server wave and take the answer (HotRing)
+            if (CUM) tk += __builtin_amdgcn_readfirstlane(tbase[il]);
             const int32_t hs = tk & (HOT_R - 1), gen3 = 3 * (tk / HOT_R);
             int *stw = hot.st + hs;
+            PF_T(h0);
             for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                     stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != gen3; ++spins) {
                 if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            PF_T(h1);
+            PF_ADD(29, h0, h1);
 #pragma unroll
             for (int c = 0; c < KC; ++c) hot.p[(size_t)hs * k + lane + 64 * c] = p[c];
             *sink_ptr(&hot.s[2 * hs], ctl, lane) = bu;
@@ -481,6 +498,9 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PF_T(h2);
+            PF_ADD(30, h1, h2);
+            PF_INC(31, 1);
             PF_INC(PF_RATINGS, 1);
             continue;
         }
@@ -490,6 +510,8 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #ifdef MFSGD_PROF
         int32_t first_ahead = 0;
 #endif
+        int32_t tb = 0;
+        if (CUM) tb = tbase[il];   // rides in front of the first poll (LDS answers a wave in issue order)
         if (STAGE) {
             // Ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in issue
             // order.  So each poll issues the ticket read AND the row reads back to back: if the ticket read
@@ -506,6 +528,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                     q[c] = (FAST || f < k) ? qs[(size_t)il * k + f] : (T)0;
                 }
                 bi = bis[il];
+                if (CUM) { tk += __builtin_amdgcn_readfirstlane(tb); tb = 0; }
                 int32_t ahead = tk - __builtin_amdgcn_readfirstlane(seen);
 #ifdef MFSGD_PROF
                 if (spins == 0) { first_ahead = ahead; }
@@ -583,6 +606,14 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         PF_ADD(PF_UPDATE, r1, r2);
     }
     PF_T(w2);
+    if (CUM && fl_cnt > 0) {
+        // Streaming kernel: this is the first run the wave walks in a new block, and the scheduler waits to hear
+        // how many runs of the previous block the wave finished - with their stores complete.  Here, just
+        // before this run's own stores, everything outstanding is at least one walk old: the drain is ~free,
+        // where in front of the walk it would have put a store round trip on the item chains this run is in.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(sink_ptr(fl_word, ctl, lane), fl_cnt);
+    }
     if (FAST) {
         // Stores the compiler does not see (untracked_store): with a tracked store pending, hipcc's wait
         // insertion treats vmcnt as out of order on gfx9-class targets and turns every later wait for a
@@ -609,23 +640,31 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis, int32_t *err, HotRing<T> hot PF_PARAM)
+                                              int *tick_done, T *qs, T *bis, int32_t *err, HotRing<T> hot, int *rt_u,
+                                              int *rt_t, int32_t run_lo, int32_t run_hi, int32_t n_hot_blk PF_PARAM)
 {
     constexpr bool HOT = STAGE && FAST;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
-    const int32_t bid = r * g.Gc + c;
-    const int32_t run_lo = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid]);
-    const int32_t run_hi = __builtin_amdgcn_readfirstlane(g.blk_run_ptr[bid + 1]);
     const int32_t c_base = c * g.ibp;
     int32_t width = (int32_t)(g.n_items - c_base);
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
-    ctl[CTL_RUN] = run_lo;  // every thread, same value
+    const int32_t nr = run_hi - run_lo;
+    const bool table = g.user_unique && nr <= RT_CAP;
+    if (table) {
+        // the block's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
+        for (int i = tid; i <= nr + 1; i += blockDim.x) {
+            const int ii = i < nr ? i : nr;
+            rt_t[i] = g.run_start[run_lo + ii];
+            rt_u[i] = i < nr ? g.run_user[run_lo + i] : 0;
+        }
+    }
+    ctl[CTL_RUN] = table ? 0 : run_lo;  // every thread, same value
     int32_t n_hot = 0;
     if (HOT) {
         if (!g.user_unique || nw < 4) hot.item = -1;   // a server needs workers beside it
-        if (hot.item >= 0) n_hot = __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[bid]);
+        if (hot.item >= 0) n_hot = n_hot_blk;
         if (tid < HOT_R) hot.st[tid] = 0;
     }
     __syncthreads();
@@ -674,7 +713,43 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         *sink_ptr(&bis[hl], ctl, lane) = bi;
         // nobody reads the item's row before the closing barrier: workers never touch it, later blocks come after
     }
-    if (g.user_unique) {
+    if (table) {
+        // A wave binds itself to TWO runs beyond the one it walks (their head loads are in flight), and claims the
+        // next only after the walk.  Claiming further ahead (the index words then came from HBM, two runs early)
+        // cost 7% of the epoch: a run claimed by a wave that is held up - a long run, a wait for an item - sits
+        // idle, and every later rating of its items waits behind it.
+        auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
+        auto index = [&](int32_t jj, RunIdx &x) {
+            const int32_t ii = jj < nr ? jj : nr;
+            x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
+        };
+        RunHead<T, KC> cur, nxt, far;
+        RunIdx x;
+        int32_t j = claim();
+        index(j, x);
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, cur);
+        int32_t jn = claim();
+        index(jn, x);
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, nxt);
+        int32_t jf = claim();
+        index(jf, x);
+        PF_T(b1);
+        PF_ADD(PF_PROLOGUE, b0, b1);
+        while (j < nr) {
+            PF_T(i0);
+            load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far);
+            PF_T(i1);
+            PF_ADD(PF_ISSUE, i0, i1);
+            walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                              tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
+            cur = nxt;
+            nxt = far;
+            j = jn;
+            jn = jf;
+            jf = claim();
+            index(jf, x);
+        }
+    } else if (g.user_unique) {
         // branch-free dequeue on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around
         // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
         // Three runs in flight per wave: walking `cur`, head loads of `nxt` issued, index words of `far`
@@ -697,8 +772,10 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         load_run<T, KC, FAST>(g, xn, P, b_u, z, k, lane, cur);
         int32_t jn = claim();
         run_index(g, real(jn), xn);
+#ifndef MFSGD_SHALLOW
         int32_t jf = claim();
         run_index(g, real(jf), xf);
+#endif
         PF_T(b1);
         PF_ADD(PF_PROLOGUE, b0, b1);
         while (j < run_hi) {
@@ -709,13 +786,19 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             PF_T(i1);
             PF_ADD(PF_ISSUE, i0, i1);
             walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                              tick_done, qs, bis, lane, err, hot PF_PASS);
+                                              tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
             cur = nxt;
+#ifdef MFSGD_SHALLOW
+            xn = xg;
+            j = jn;
+            jn = jg;
+#else
             xn = xf;
             xf = xg;
             j = jn;
             jn = jf;
             jf = jg;
+#endif
         }
     } else {
         // a user may own several runs of this block: all of them go to one wave, in stored order
@@ -726,7 +809,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             run_index(g, j, x);
             load_run<T, KC, false>(g, x, P, b_u, z, k, lane, cur);
             walk_run<T, KC, STAGE, false, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                                 tick_done, qs, bis, lane, err, hot PF_PASS);
+                                                 tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -790,7 +873,9 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
 #endif
     const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), -1};
     process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
-                                       bis, s.err, hot PF_PASS);
+                                       bis, s.err, hot, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
+                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
+                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), 0 PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -803,6 +888,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
     unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
+    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, ratings of the served item of block (r, c)
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
     const int tid = threadIdx.x, lane = tid & 63;
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
@@ -830,13 +916,18 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
         // rows with an empty block need no visit
         int32_t mine = 0;
         for (int r = tid; r < g.Gr; r += blockDim.x) {
-            const bool empty = g.blk_run_ptr[r * g.Gc + c] == g.blk_run_ptr[r * g.Gc + c + 1];
+            const int32_t lo = g.blk_run_ptr[r * g.Gc + c], hi = g.blk_run_ptr[r * g.Gc + c + 1];
+            const bool empty = lo == hi;
+            rowrun[3 * r] = lo;
+            rowrun[3 * r + 1] = hi;
+            rowrun[3 * r + 2] = g.blk_hot_cnt[r * g.Gc + c];
             row_done[r] = empty ? 1 : 0;
             mine += empty ? 0 : 1;
         }
         atomicAdd(&ctl[CTL_REMAIN], mine);
         stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
+        int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
         const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
                              __builtin_amdgcn_readfirstlane(g.col_hot[c])};
@@ -844,15 +935,36 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
             if (sched_wave) {
                 int32_t found = -1;
                 const int32_t remain = __builtin_amdgcn_readfirstlane(ctl[CTL_REMAIN]);
+                auto release = [&]() {
+                    // every wave drained its stores before the barrier that ended process_block
+                    if (held >= 0) {
+                        if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        held = -1;
+                    }
+                };
                 for (int sweeps = 0; remain > 0 && found < 0; ++sweeps) {
                     if (sweeps >= SPIN_LOCK_SWEEPS) { atomicOr(s.err, 2); break; }
                     // 64 rows per step: every lane looks at one row of the rotation that starts at `pos`
                     for (int32_t base = 0; base < g.Gr && found < 0; base += 64) {
                         int32_t r = pos + base + lane;
                         while (r >= g.Gr) r -= g.Gr;
-                        const bool cand = base + lane < g.Gr && !row_done[r];
+                        bool cand = base + lane < g.Gr && !row_done[r];
+                        if (__ballot(cand) == 0) continue;
+                        // peek at the 64 lock words with one vector atomic (answered where the CAS is), then try
+                        // only rows that look free, starting at a pseudo-random one: workgroups that look at the
+                        // same stretch see the same free rows and would all race for the lowest
+                        int32_t *pw = cand ? &s.row_lock[r] : (int32_t *)(ctl + CTL_SINK + 2 * lane);
+                        const int32_t lockv = __hip_atomic_fetch_or(pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cand = cand && lockv == 0;
                         unsigned long long mask = __ballot(cand);
-                        while (mask != 0 && found < 0) {
+                        int32_t skip = (int32_t)(mix32((uint32_t)(c * 977 + remain) + s.seed) %
+                                                 (uint32_t)(__builtin_popcountll(mask) | 1));
+                        unsigned long long low = 0;
+                        while (skip-- > 0 && (mask & (mask - 1)) != 0) { low |= mask & (0 - mask); mask &= mask - 1; }
+                        while ((mask | low) != 0 && found < 0) {
+                            if (mask == 0) { mask = low; low = 0; }
                             const int l = __builtin_ctzll(mask);
                             mask &= mask - 1;
                             const int32_t rc = __builtin_amdgcn_readlane(r, l);
@@ -865,7 +977,10 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
                             if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;   // unchanged <=> swapped
                         }
                     }
-                    if (found < 0) __builtin_amdgcn_s_sleep(32);
+                    if (found < 0) {
+                        release();   // never wait for a row while holding one
+                        __builtin_amdgcn_s_sleep(32);
+                    }
                 }
                 if (found >= 0) {
                     row_done[found] = 1;
@@ -886,16 +1001,22 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
             }
             __syncthreads();
             const int32_t r = __builtin_amdgcn_readfirstlane(ctl[CTL_ROW]);
+            if (sched_wave) {
+                // the finished block's row goes back while the other waves already start on the next block
+                if (held >= 0) {
+                    if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                held = r;
+            }
             if (r < 0) break;
             if (!(s.dbg & 4))
                 process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
-                                                  ctl, tick_done, qs, bis, s.err, hot PF_PASS);
-            if (sched_wave) {
-                // release: every wave drained its stores before the barrier that ended process_block
-                if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&s.row_lock[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+                                                  ctl, tick_done, qs, bis, s.err, hot, (int *)(smem + lp.rt_u),
+                                                  (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
+                                                  __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
+                                                  __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]) PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -907,6 +1028,378 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
     unsigned long long *out = (unsigned long long *)(s.col_clock + 2 * g.Gc);
     for (int i = 0; i < PF_SLOTS; ++i)
         atomicAdd((unsigned long long *)sink_ptr(out + i, ctl, lane), pf[i]);
+#endif
+}
+
+// ------------------------------------------------------------------------------ streaming free-block kernel
+// Same schedule, same results as k_epoch_free, without a workgroup barrier per block.  Measured on the
+// netflix shape, k_epoch_free spends ~18 us per block outside the walk (lock search and fences, pipeline fill,
+// closing barrier and the imbalance in front of it) against ~20 us inside it.  Here a workgroup streams
+// through its column:
+//   wave 0 (scheduler) locks user stripes AHEAD of the workers, copies each locked block's run table into LDS,
+//     extends the per-item ticket bases, publishes the block, and releases stripes whose runs are all done;
+//   waves 1.. (workers) claim runs from ONE counter that runs over the whole tenure (run g belongs to the
+//     published block whose cumulative run range holds g), so they never meet at a block boundary;
+//   the last wave serves the stripe's most rated item (HotRing) across blocks, its row in registers for the
+//     whole tenure, when the stripe has such an item.
+// Tickets are cumulative over the tenure: a rating waits for tick_done[item] == base_of_its_block[item] + ticket.
+// A worker tells the scheduler how many runs of a block it finished when it first walks a run of another
+// block or runs out of work, after draining its stores (vmcnt(0)): once per block and wave, nobody else waits.
+constexpr int BQ = 4;         // blocks a workgroup may hold ahead (queue slots)
+enum { CTL_TAIL = 4, CTL_END = 5, CTL_CLAIM = 6 };
+enum { E_ROW = 0, E_NRUNS = 1, E_DONE = 2, E_WORDS = 4 };
+
+struct StreamPlan {  // byte offsets in dynamic LDS (multiples of 16)
+    uint32_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, base, ent, cum, rt_u, rt_t, rowrun, total;
+    int32_t trigger; // the next stripe is looked for once this many 256ths of the newest block's runs are claimed
+    int32_t depth;   // user stripes a workgroup may hold at once (1..BQ): rows are scarce when Gr is close to the grid size
+};
+
+template <typename T>
+StreamPlan stream_plan(int32_t ibp, int32_t Gr, int32_t k)
+{
+    auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    StreamPlan p{};
+    size_t o = 0;
+    p.ctl = o; o = up(o + CTL_WORDS * 4);
+    p.tick = o; o = up(o + (size_t)ibp * 4);
+    p.rowdone = o; o = up(o + (size_t)Gr);
+    p.qs = o; o = up(o + (size_t)ibp * k * sizeof(T));
+    p.bis = o; o = up(o + (size_t)ibp * sizeof(T));
+    p.ring_st = o; o = up(o + (size_t)HOT_R * 4);
+    p.ring_s = o; o = up(o + (size_t)HOT_R * 2 * sizeof(T));
+    p.ring_p = o; o = up(o + (size_t)HOT_R * k * sizeof(T));
+    p.base = o; o = up(o + (size_t)BQ * ibp * 4);
+    p.ent = o; o = up(o + (size_t)BQ * E_WORDS * 4);
+    p.cum = o; o = up(o + ((size_t)Gr + 1) * 4);
+    p.rt_u = o; o = up(o + (size_t)BQ * RT_CAP * 4);
+    p.rt_t = o; o = up(o + (size_t)BQ * (RT_CAP + 1) * 4);
+    p.rowrun = o; o = up(o + (size_t)Gr * 8);
+    p.total = (uint32_t)o;
+    return p;
+}
+
+template <typename T, int KC>
+__global__ __launch_bounds__(1024, 8) void k_epoch_stream(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, T alpha, T beta1,
+                                                       T beta2, int variant, int k, StreamPlan lp, SchedView s)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *ctl = (int *)(smem + lp.ctl);
+    int *tick_done = (int *)(smem + lp.tick);
+    unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
+    T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
+    int *base = (int *)(smem + lp.base), *ent = (int *)(smem + lp.ent), *cum = (int *)(smem + lp.cum);
+    int *rt_u = (int *)(smem + lp.rt_u), *rt_t = (int *)(smem + lp.rt_t);
+    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][2] first run and run count of block (r, c)
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const T *z = nullptr;
+#ifdef MFSGD_PROF
+    unsigned long long pf[PF_SLOTS] = {};
+#endif
+    for (;;) {
+        if (wave == 0) {
+            const int32_t ci = __builtin_amdgcn_readlane(
+                __hip_atomic_fetch_add(sink_ptr(&s.counters[0], ctl, lane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
+            int32_t col = -1;
+            if (ci < g.n_cols) {
+                col = __builtin_amdgcn_readfirstlane(g.col_order[ci]);
+                s.col_clock[2 * col] = (long long)__builtin_amdgcn_s_memrealtime();
+            }
+            ctl[CTL_COL] = col;
+            ctl[CTL_REMAIN] = 0;
+            ctl[CTL_TAIL] = 0;
+            ctl[CTL_END] = 0;
+            ctl[CTL_CLAIM] = 0;
+        }
+        __syncthreads();
+        const int32_t c = __builtin_amdgcn_readfirstlane(ctl[CTL_COL]);
+        if (c < 0) break;
+        const int32_t c_base = c * g.ibp;
+        int32_t width = (int32_t)(g.n_items - c_base);
+        if (width > g.ibp) width = g.ibp;
+        int32_t mine = 0;
+        for (int r = tid; r < g.Gr; r += blockDim.x) {
+            const int32_t lo = g.blk_run_ptr[r * g.Gc + c], hi = g.blk_run_ptr[r * g.Gc + c + 1];
+            const bool empty = lo == hi;
+            rowrun[2 * r] = lo;
+            rowrun[2 * r + 1] = hi - lo;
+            row_done[r] = empty ? 1 : 0;
+            mine += empty ? 0 : 1;
+        }
+        atomicAdd(&ctl[CTL_REMAIN], mine);
+        for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
+        if (tid < HOT_R) ((int *)(smem + lp.ring_st))[tid] = 0;
+        if (tid < BQ * E_WORDS) ent[tid] = 0;
+        if (tid == 0) cum[0] = 0;
+        stripe_load<T, true>(g, c, Q, b_i, k, qs, bis);
+        __syncthreads();
+        const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
+                             __builtin_amdgcn_readfirstlane(g.col_hot[c])};
+        const int32_t hot_total = __builtin_amdgcn_readfirstlane(g.col_hot_deg[c]);
+        if (wave == 0) {
+            // ------------------------------------------------------------------ scheduler
+            int32_t seq = 0, rel = 0, prev_t0 = 0, prev_t1 = 0, ended = 0;
+            int32_t remain = __builtin_amdgcn_readfirstlane(ctl[CTL_REMAIN]);
+            int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
+            for (int idle = 0;;) {
+                bool progressed = false;
+                PF_T(s0);
+                if (rel < seq) {   // oldest held block: all of its runs walked and their stores drained?
+                    const int es = rel & (BQ - 1);
+                    const int32_t done = __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(&ent[es * E_WORDS + E_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const int32_t nr = __builtin_amdgcn_readfirstlane(ent[es * E_WORDS + E_NRUNS]);
+                    if (done == nr) {
+                        const int32_t row = __builtin_amdgcn_readfirstlane(ent[es * E_WORDS + E_ROW]);
+                        if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&s.row_lock[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ++rel;
+                        progressed = true;
+                    }
+                }
+                PF_T(s1);
+                PF_ADD(0, s0, s1);
+                bool want = remain > 0 && seq - rel < lp.depth;
+                if (want && seq > rel) {   // something is queued: take the next stripe only when it will be needed soon
+                    const int32_t claimed = __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(&ctl[CTL_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const int32_t c0 = __builtin_amdgcn_readfirstlane(cum[seq - 1]), c1 = __builtin_amdgcn_readfirstlane(cum[seq]);
+                    want = claimed >= c0 + (((c1 - c0) * lp.trigger) >> 8);
+                }
+                if (want) {   // one sweep over the rows still to do; only rows that look free are tried
+                    int32_t found = -1;
+                    for (int32_t bs = 0; bs < g.Gr && found < 0; bs += 64) {
+                        int32_t r = pos + bs + lane;
+                        while (r >= g.Gr) r -= g.Gr;
+                        bool cand = bs + lane < g.Gr && !row_done[r];
+                        // the peek is an atomic RMW on purpose: it is answered where the CAS is (a load with agent
+                        // scope was seen returning 0 for words whose CAS then failed, a dozen times per block)
+                        int32_t *pw = cand ? &s.row_lock[r] : (int32_t *)(ctl + CTL_SINK + 2 * lane);
+                        const int32_t lockv = __hip_atomic_fetch_or(pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        PF_INC(24, 1);
+                        PF_INC(27, __builtin_popcountll(__ballot(cand)));
+                        cand = cand && lockv == 0;
+                        unsigned long long mask = __ballot(cand);
+                        PF_INC(28, __builtin_popcountll(mask));
+                        // Workgroups that look at the same stretch of rows see the same free ones: each starts at
+                        // its own pseudo-random member of the set, or they would all race for the lowest
+                        int32_t skip = (int32_t)(mix32((uint32_t)(c * 977 + seq) + s.seed) % (uint32_t)(__builtin_popcountll(mask) | 1));
+                        unsigned long long low = 0;
+                        while (skip-- > 0 && (mask & (mask - 1)) != 0) { low |= mask & (0 - mask); mask &= mask - 1; }
+                        while ((mask | low) != 0 && found < 0) {
+                            if (mask == 0) { mask = low; low = 0; }
+                            const int l = __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            const int32_t rc = __builtin_amdgcn_readlane(r, l);
+                            int32_t expect = 0;
+                            int32_t *w = sink_ptr(&s.row_lock[rc], ctl, lane);
+                            if (lane != 0) expect = 0x7fffffff;   // value select, not control flow
+                            __hip_atomic_compare_exchange_strong(w, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                            if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;
+                            PF_INC(26, 1);
+                            PF_INC(25, found < 0 ? 1 : 0);
+                        }
+                    }
+                    PF_T(s2);
+                    PF_ADD(1, s1, s2);
+                    PF_INC(13, found < 0 ? 1 : 0);
+                    if (found >= 0) {
+                        PF_INC(12, 1);
+                        row_done[found] = 1;
+                        pos = found + 1 == g.Gr ? 0 : found + 1;
+                        --remain;
+                        if (s.order_log) {
+                            const int32_t slot = __builtin_amdgcn_readlane(
+                                __hip_atomic_fetch_add(sink_ptr(&s.counters[1], ctl, lane), 1, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT), 0);
+                            s.order_log[2 * (s.log_base + slot)] = found;
+                            s.order_log[2 * (s.log_base + slot) + 1] = c;
+                        }
+                        // the grid arrays are never written: their loads need not wait for the acquire below
+                        const int32_t run_lo = __builtin_amdgcn_readfirstlane(rowrun[2 * found]);
+                        const int32_t nr = __builtin_amdgcn_readfirstlane(rowrun[2 * found + 1]);
+                        const int es = seq & (BQ - 1), ps = (seq - 1) & (BQ - 1);
+                        // run table of the block; entry nr closes the last run
+                        for (int32_t i = lane; i <= nr; i += 64) {
+                            rt_t[es * (RT_CAP + 1) + i] = g.run_start[run_lo + i];
+                            rt_u[es * RT_CAP + (i < nr ? i : 0)] = g.run_user[run_lo + (i < nr ? i : 0)];
+                        }
+                        // ticket bases of this block = bases of the previous one + what the previous one holds
+                        for (int32_t il = lane; il < width; il += 64) base[es * g.ibp + il] = seq ? base[ps * g.ibp + il] : 0;
+                        for (int32_t t = prev_t0 + lane; t < prev_t1; t += 64) {
+                            const int32_t il = g.item[t] - c_base;
+                            atomicMax(&base[es * g.ibp + il], base[ps * g.ibp + il] + g.tick[t] + 1);
+                        }
+                        prev_t0 = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);
+                        prev_t1 = __builtin_amdgcn_readfirstlane(g.run_start[run_lo + nr]);
+                        ent[es * E_WORDS + E_ROW] = found;      // every lane, same value
+                        ent[es * E_WORDS + E_NRUNS] = nr;
+                        ent[es * E_WORDS + E_DONE] = 0;
+                        const int32_t cprev = __builtin_amdgcn_readfirstlane(cum[seq]);
+                        cum[seq + 1] = cprev + nr;
+                        PF_T(s3);
+                        PF_ADD(2, s2, s3);
+                        // acquire: drop this CU's L1 (and stale L2 lines) so the previous holder's rows are re-read
+                        if (!(s.dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        ++seq;
+                        __hip_atomic_store(&ctl[CTL_TAIL], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        progressed = true;
+                        PF_T(s4);
+                        PF_ADD(7, s3, s4);
+                    }
+                }
+                if (remain == 0 && !ended) {
+                    __hip_atomic_store(&ctl[CTL_END], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ended = 1;
+                }
+                if (ended && rel == seq) break;
+                if (progressed) idle = 0;
+                else {
+                    if (++idle >= SPIN_TICKET_MAX) { atomicOr(s.err, 2); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    PF_INC(8, 1);
+                }
+            }
+        } else if (wave == nw - 1 && hot.item >= 0) {
+            // ------------------------------------------------------------------ server of the most rated item
+            const int32_t hl = hot.item - c_base;
+            T q[KC], zz[KC], rp[KC], bi, rbu, rr;
+            int32_t seen;
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
+            bi = bis[hl];
+            auto fetch = [&](int32_t hs) {
+                seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
+                rbu = hot.s[2 * hs];
+                rr = hot.s[2 * hs + 1];
+            };
+            __builtin_amdgcn_s_setprio(3);
+            fetch(0);
+            for (int32_t t = 0; t < hot_total; ++t) {
+                const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
+                for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
+                    if (spins >= SPIN_TICKET_MAX) { atomicOr(s.err, 1); break; }
+                    if (spins > 4) __builtin_amdgcn_s_sleep(1);
+                    fetch(hs);
+                }
+                T cp[KC], pn[KC];
+#pragma unroll
+                for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
+                T cbu = rbu;
+                const T rest = rr - b - cbu;
+                fetch((t + 1) & (HOT_R - 1));
+                const T e = sgd_step<T, KC>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
+                cbu += alpha * (e - beta1 * cbu);
+#pragma unroll
+                for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
+                *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
+            *sink_ptr(&bis[hl], ctl, lane) = bi;
+        } else {
+            // ------------------------------------------------------------------ worker
+            auto claim = [&](bool take) {
+                return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_CLAIM], ctl, lane), take ? 1 : 0), 0);
+            };
+            RunHead<T, KC> cur, h1, h2, nh;
+            cur.real = h1.real = h2.real = 0;
+            cur.u = h1.u = h2.u = 0; cur.t0 = h1.t0 = h2.t0 = 1; cur.t1 = h1.t1 = h2.t1 = 1;
+            cur.seq = h1.seq = h2.seq = -1; cur.es = h1.es = h2.es = 0;
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) { cur.p[cc] = h1.p[cc] = h2.p[cc] = 0; cur.zz[cc] = h1.zz[cc] = h2.zz[cc] = 0; }
+            cur.bu = h1.bu = h2.bu = 0; cur.m_item = h1.m_item = h2.m_item = 0; cur.m_tick = h1.m_tick = h2.m_tick = 0;
+            cur.m_val = h1.m_val = h2.m_val = 0;
+            int32_t e = 0;               // lowest block sequence number that can hold this wave's pending claim
+            int32_t gcl = claim(true);   // pending claim: a run number counted over the whole tenure
+            int32_t last_seq = -1, last_es = 0, cnt = 0;
+            auto flush = [&]() {   // tell the scheduler how many runs of block last_seq this wave has finished
+                if (cnt > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    atomicAdd(sink_ptr(&ent[last_es * E_WORDS + E_DONE], ctl, lane), cnt);
+                    cnt = 0;
+                }
+            };
+            for (int idle = 0;;) {
+                PF_T(w0);
+                PF_INC(22, 1);
+                // END is read before TAIL: once END is seen the TAIL read behind it is final
+                const int32_t endf = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&ctl[CTL_END], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order; the LDS itself is in order
+                const int32_t tail = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&ctl[CTL_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                while (e < tail && gcl >= __builtin_amdgcn_readfirstlane(cum[e + 1])) ++e;
+                const bool ok = e < tail;
+                RunIdx x;
+                x.j = 0; x.u = 0; x.t0 = 1; x.t1 = 1;   // a hole: loads go to valid addresses and are never used
+                const int es = e & (BQ - 1);
+                if (ok) {
+                    const int32_t j = gcl - __builtin_amdgcn_readfirstlane(cum[e]);
+                    x.u = rt_u[es * RT_CAP + j];
+                    x.t0 = rt_t[es * (RT_CAP + 1) + j];
+                    x.t1 = rt_t[es * (RT_CAP + 1) + j + 1];
+                }
+                load_run<T, KC, true>(g, x, P, b_u, z, k, lane, nh);
+                nh.real = ok ? 1 : 0; nh.seq = e; nh.es = es;
+                const int32_t nxt_claim = claim(ok);
+                if (ok) gcl = nxt_claim;
+                const bool nothing = !cur.real && !h1.real && !h2.real && !ok;
+                PF_T(w1);
+                PF_ADD(19, w0, w1);
+                if (cur.real) {
+                    int *fl_word = nullptr;
+                    int32_t fl_cnt = 0;
+                    if (cur.seq != last_seq) {   // first run of another block: report the old one from inside the walk
+                        fl_word = &ent[last_es * E_WORDS + E_DONE];
+                        fl_cnt = cnt;
+                        cnt = 0; last_seq = cur.seq; last_es = cur.es;
+                    }
+                    PF_T(w2);
+                    PF_ADD(20, w1, w2);
+                    walk_run<T, KC, true, true, true, true>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant,
+                                                            k, ctl, tick_done, qs, bis, lane, s.err, hot,
+                                                            base + cur.es * g.ibp, fl_word, fl_cnt PF_PASS);
+                    ++cnt;
+                    PF_T(w3);
+                    PF_ADD(21, w2, w3);
+                }
+#ifdef MFSGD_SHALLOW
+                cur = h1; h1 = nh;
+#else
+                cur = h1; h1 = h2; h2 = nh;
+#endif
+                if (nothing) {
+                    PF_INC(23, 1);
+                    flush();
+                    if (endf) break;   // no block will be published any more and the claim lies behind the last one
+                    if (++idle >= SPIN_TICKET_MAX) { atomicOr(s.err, 1); break; }
+                    __builtin_amdgcn_s_sleep(8);
+                } else idle = 0;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        stripe_store<T, true>(g, c, Q, b_i, k, qs, bis);
+        if (wave == 0) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#ifdef MFSGD_PROF
+    {
+        unsigned long long *out = (unsigned long long *)(s.col_clock + 2 * g.Gc);
+        for (int i = 0; i < PF_SLOTS; ++i) atomicAdd((unsigned long long *)sink_ptr(out + i, ctl, lane), pf[i]);
+    }
 #endif
 }
 
@@ -948,6 +1441,28 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         n_wg = prop.multiProcessorCount * per_cu;
     }
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
+    if (STAGE && fast && gv.user_unique && waves >= 4 && G->max_block_runs <= RT_CAP && getenv("MFSGD_STREAM")) {   // experimental, see DESIGN.md
+        StreamPlan sp = stream_plan<T>(gv.ibp, gv.Gr, k);
+        const char *dep = getenv("MFSGD_STREAM_DEPTH");
+        sp.depth = dep ? atoi(dep) : 2;
+        sp.depth = std::max(1, std::min(sp.depth, (int32_t)BQ));
+        const char *trg = getenv("MFSGD_STREAM_TRIGGER");
+        sp.trigger = trg ? atoi(trg) : 64;
+        if (sp.total <= (size_t)160 * 1024) {
+            auto sk = k_epoch_stream<T, KC>;
+            MF_HIP(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.total));
+            for (int it = 0; it < iters; ++it) {
+                MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
+                MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
+                SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it),
+                            G->counters + 8, G->col_clock, dbg};
+                hipLaunchKernelGGL(sk, dim3(n_wg), dim3(threads), sp.total, st, gv, P, Q, b_u, b_i, b, alpha, beta1, beta2,
+                                   variant, k, sp, s);
+                MF_LAUNCH_CHECK();
+            }
+            return MFSGD_OK;
+        }
+    }
     for (int it = 0; it < iters; ++it) {
         MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
         MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
@@ -975,7 +1490,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt};
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->col_hot_deg};
     const bool dynamic = schedule == 1;
     const size_t cap = (size_t)160 * 1024;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
@@ -1008,7 +1523,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt};
+                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt, g->col_hot_deg};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1062,6 +1577,8 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
         for (int i = 0; i < PF_SLOTS; ++i)
+            fprintf(stderr, "slot %2d %14llu\n", i, pf[i]);
+        for (int i = 0; i < PF_SLOTS; ++i)
             if (names[i]) fprintf(stderr, "prof %-13s %14llu  (%.1f%% of tenure)\n", names[i], pf[i], 100.0 * pf[i] / (double)pf[PF_TENURE]);
     }
 #endif
@@ -1103,6 +1620,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->col_hot, (size_t)Gc)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
+    MF_HIP(dalloc(&G->col_hot_deg, (size_t)Gc));
+    MF_HIP(hipMemsetAsync(G->col_hot_deg, 0, sizeof(int32_t) * (size_t)Gc, st));
     MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc, st));
     MF_HIP(hipMemsetAsync(G->blk_hot_cnt, 0, sizeof(int32_t) * (size_t)nb, st));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
@@ -1191,6 +1710,9 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     hipLaunchKernelGGL(k_blk_run_ptr, dim3(nblk(nb + 1)), dim3(256), 0, st, blk_ptr.as<int32_t>(), excl.as<int32_t>(),
                        nb, n, n_runs, G->blk_run_ptr);
     MF_LAUNCH_CHECK();
+    MF_HIP(hipMemcpyAsync(h_blk.data(), G->blk_run_ptr, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < nb; ++i) G->max_block_runs = std::max(G->max_block_runs, h_blk[i + 1] - h_blk[i]);
     MF_HIP(hipMemcpyAsync(h_blk.data(), blk_ptr.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
     // 4. tickets: rank of a rating among the ratings of its (block, item), in stored order
     {
@@ -1240,7 +1762,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         hipLaunchKernelGGL(k_item_deg, dim3(nblk(n)), dim3(256), 0, st, G->item, n, deg.as<int32_t>());
         MF_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
-                           G->col_hot);
+                           G->col_hot, G->col_hot_deg);
         MF_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_blk_hot, dim3(nblk(n)), dim3(256), 0, st, bkey, G->item, n, (int32_t)Gc, G->col_hot,
                            G->blk_hot_cnt);
