@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--renumber", default="balanced", choices=["balanced", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20240611)
+    ap.add_argument("--swap-roles", action="store_true",
+                    help="experiment: feed the data with users and items swapped (which side is LDS-stationary)")
     args = ap.parse_args()
 
     import torch
@@ -128,11 +130,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MFSGD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 leg on a one-GPU box
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     _abi.require_gpu()
     train, test, U, I, k = synth(torch, args.workload, args.seed + sorted(WORKLOADS).index(args.workload), args.scale)
+    if args.swap_roles:
+        train = train[:, [1, 0, 2]].contiguous(); test = test[:, [1, 0, 2]].contiguous(); U, I = I, U
     if args.k:
         k = args.k
     if world > 1:

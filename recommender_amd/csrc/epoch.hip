@@ -301,7 +301,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    size_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, rt_u, rt_t, total;
+    uint32_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, ring_ui, rt_u, rt_t, total;
 };
 constexpr int RT_CAP = 512;   // runs per block the LDS run table takes
 
@@ -313,11 +313,14 @@ constexpr int RT_CAP = 512;   // runs per block the LDS run table takes
 // slots in ticket order (the next request is prefetched while the current one is computed, so a link costs
 // the arithmetic only), writes the updated user row and bias back into the slot, and the worker picks them up.
 // Slot state word: 3g = free for generation g = ticket / HOT_R, 3g+1 = request posted, 3g+2 = answered.
+// When the item's rating is the LAST of the user's run (most runs have one rating) the worker does not wait:
+// the server itself stores the new user row and bias to HBM and frees the slot, the worker moves on.
 constexpr int HOT_R = 16;   // >= waves per workgroup: a worker has at most one request posted
 template <typename T> struct HotRing {
     int *st;       // [HOT_R]
     T *s;          // [HOT_R][2]  {b_u, rating}
     T *p;          // [HOT_R][k]
+    int *ui;       // [HOT_R][2]  {user, 1 = the worker wants the row back | 0 = last rating of its run: the server stores it}
     int32_t item;  // global id of the served item, -1: nobody is served in this stripe
 };
 
@@ -336,9 +339,10 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.ring_st = o; o = up(o + (stage ? (size_t)HOT_R * 4 : 0));
     p.ring_s = o; o = up(o + (stage ? (size_t)HOT_R * 2 * sizeof(T) : 0));
     p.ring_p = o; o = up(o + (stage ? (size_t)HOT_R * k * sizeof(T) : 0));
+    p.ring_ui = o; o = up(o + (stage ? (size_t)HOT_R * 8 : 0));
     p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.rt_t = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
-    p.total = o;
+    p.total = (uint32_t)std::min<size_t>(o, 0xffffffffu);
     return p;
 }
 
@@ -419,19 +423,19 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
 
 // One rating (numba_methods.py:17-22 without the implicit write-back): error, new user row `pn`, new item row
 // in place, new item bias in place.  The caller settles b_u (it needs `e` only).
-template <typename T, int KC>
+template <typename T, int KC, bool HASZ>
 __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q)[KC], T &bi, T rest, T alpha, T beta1,
                                       T beta2, int variant, T (&pn)[KC])
 {
     T part = 0;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) part += q[c] * (p[c] + zz[c]);
+    for (int c = 0; c < KC; ++c) part += q[c] * (HASZ ? p[c] + zz[c] : p[c]);
     const T e = rest - bi - wave_sum(part);
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         pn[c] = p[c] + alpha * (e * q[c] - beta2 * p[c]);
         const T pu = variant == 0 ? pn[c] : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
-        q[c] = q[c] + alpha * (e * (pu + zz[c]) - beta2 * q[c]);
+        q[c] = q[c] + alpha * (e * (HASZ ? pu + zz[c] : pu) - beta2 * q[c]);
     }
     bi += alpha * (e - beta1 * bi);
     return e;
@@ -484,8 +488,15 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             for (int c = 0; c < KC; ++c) hot.p[(size_t)hs * k + lane + 64 * c] = p[c];
             *sink_ptr(&hot.s[2 * hs], ctl, lane) = bu;
             *sink_ptr(&hot.s[2 * hs + 1], ctl, lane) = r;
+            const bool handed = !CUM && t == t1 - 1;   // last rating of the run: the server stores row and bias
+            *sink_ptr(&hot.ui[2 * hs], ctl, lane) = u;
+            *sink_ptr(&hot.ui[2 * hs + 1], ctl, lane) = handed ? 0 : 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS keeps a wave's stores in order
             __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (handed) {
+                PF_INC(PF_RATINGS, 1);
+                return;
+            }
             for (int spins = 0;; ++spins) {
                 const int32_t seen = __hip_atomic_load(stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -578,7 +589,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #endif
         PF_INC(PF_RATINGS, 1);
         T pn[KC];
-        const T e = sgd_step<T, KC>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
+        const T e = sgd_step<T, KC, !FAST>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -635,6 +646,73 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     PF_ADD(PF_TAIL, w2, w3);
 }
 
+// The server wave's loop (HotRing): `n` requests in ticket order starting at cumulative ticket 0.
+template <typename T, int KC>
+__device__ __forceinline__ void serve_hot(const HotRing<T> &hot, int32_t n, int32_t hl, T *qs, T *bis, int k, int lane,
+                                          int *ctl, T b, T alpha, T beta1, T beta2, int variant, T *__restrict__ P,
+                                          T *__restrict__ b_u, int32_t *err, bool pf_on PF_PARAM)
+{
+    T q[KC], zz[KC], rp[KC], bi, rbu, rr;
+    int32_t seen, ru, rneed;
+#pragma unroll
+    for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
+    bi = bis[hl];
+    auto fetch = [&](int32_t hs) {   // state word first: LDS serves a wave's reads in order
+        seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
+        rbu = hot.s[2 * hs];
+        rr = hot.s[2 * hs + 1];
+        ru = hot.ui[2 * hs];
+        rneed = hot.ui[2 * hs + 1];
+    };
+    __builtin_amdgcn_s_setprio(3);
+    fetch(0);
+    PF_T(sv0);
+    for (int32_t t = 0; t < n; ++t) {
+        const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
+        PF_T(sv1);
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+            if (spins > 4) __builtin_amdgcn_s_sleep(1);
+            fetch(hs);
+            if (pf_on) PF_INC(27, 1);
+        }
+        PF_T(sv2);
+        if (pf_on) { PF_ADD(25, sv1, sv2); PF_INC(26, 1); }
+        T cp[KC], pn[KC];
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
+        T cbu = rbu;
+        const T rest = rr - b - cbu;
+        const int32_t cu = __builtin_amdgcn_readfirstlane(ru);
+        const bool need = __builtin_amdgcn_readfirstlane(rneed) != 0;
+        fetch((t + 1) & (HOT_R - 1));   // the next request, if it is already there, arrives behind the arithmetic
+        const T e = sgd_step<T, KC, false>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
+        cbu += alpha * (e - beta1 * cbu);
+        if (need) {   // the run goes on: hand row and bias back
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
+            *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {      // the run ends here: store for the worker (drained by this wave before the block's barrier)
+            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            T *prow = P + (int64_t)cu * k;
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) untracked_store(prow + lane + 64 * cc, pn[cc]);
+            untracked_store(&b_u[cu], cbu);   // all lanes, same word
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    PF_T(sv3);
+    if (pf_on) PF_ADD(24, sv0, sv3);
+#pragma unroll
+    for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
+    *sink_ptr(&bis[hl], ctl, lane) = bi;
+}
+
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
 template <typename T, int KC, bool STAGE, bool FAST>
@@ -650,74 +728,41 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     int32_t width = (int32_t)(g.n_items - c_base);
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
-    const int32_t nr = run_hi - run_lo;
-    const bool table = g.user_unique && nr <= RT_CAP;
-    if (table) {
-        // the block's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
-        for (int i = tid; i <= nr + 1; i += blockDim.x) {
-            const int ii = i < nr ? i : nr;
-            rt_t[i] = g.run_start[run_lo + ii];
-            rt_u[i] = i < nr ? g.run_user[run_lo + i] : 0;
-        }
-    }
-    ctl[CTL_RUN] = table ? 0 : run_lo;  // every thread, same value
+    const bool uniq = FAST || g.user_unique;     // host side: FAST kernels are only launched on user-unique grids
     int32_t n_hot = 0;
     if (HOT) {
-        if (!g.user_unique || nw < 4) hot.item = -1;   // a server needs workers beside it
+        // a server needs workers beside it; a block too long for one run table is walked in chunks with barriers
+        // between them, which a serving wave could not attend
+        if (nw < 4 || run_hi - run_lo > RT_CAP) hot.item = -1;
         if (hot.item >= 0) n_hot = n_hot_blk;
         if (tid < HOT_R) hot.st[tid] = 0;
     }
+    if (uniq) {
+    for (int32_t lo = run_lo; lo < run_hi; lo += RT_CAP) {   // one trip unless the block has more than RT_CAP runs
+    const int32_t nr = run_hi - lo < RT_CAP ? run_hi - lo : RT_CAP;
+    // the chunk's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
+    for (int i = tid; i <= nr + 1; i += blockDim.x) {
+        const int ii = i < nr ? i : nr;
+        rt_t[i] = g.run_start[lo + ii];
+        rt_u[i] = i < nr ? g.run_user[lo + i] : 0;
+    }
+    ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
     if (HOT && n_hot > 0 && __builtin_amdgcn_readfirstlane(wave) == nw - 1) {
         // ---- server of the stripe's most rated item (HotRing): row and bias in registers for the whole block
-        const int32_t hl = hot.item - c_base;
-        T q[KC], zz[KC], rp[KC], bi, rbu, rr;
-        int32_t seen;
-#pragma unroll
-        for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
-        bi = bis[hl];
-        auto fetch = [&](int32_t hs) {   // state word first: LDS serves a wave's reads in order
-            seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
-            rbu = hot.s[2 * hs];
-            rr = hot.s[2 * hs + 1];
-        };
-        __builtin_amdgcn_s_setprio(3);
-        fetch(0);
-        for (int32_t t = 0; t < n_hot; ++t) {
-            const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
-            for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                if (spins > 4) __builtin_amdgcn_s_sleep(1);
-                fetch(hs);
-            }
-            T cp[KC], pn[KC];
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
-            T cbu = rbu;
-            const T rest = rr - b - cbu;
-            fetch((t + 1) & (HOT_R - 1));   // the next request, if it is already there, arrives behind the arithmetic
-            const T e = sgd_step<T, KC>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
-            cbu += alpha * (e - beta1 * cbu);
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
-            *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
-        *sink_ptr(&bis[hl], ctl, lane) = bi;
+        serve_hot<T, KC>(hot, n_hot, hot.item - c_base, qs, bis, k, lane, ctl, b, alpha, beta1, beta2, variant, P, b_u, err,
+                         n_hot >= 150 PF_PASS);
         // nobody reads the item's row before the closing barrier: workers never touch it, later blocks come after
     }
-    if (table) {
+    {
         // A wave binds itself to TWO runs beyond the one it walks (their head loads are in flight), and claims the
         // next only after the walk.  Claiming further ahead (the index words then came from HBM, two runs early)
         // cost 7% of the epoch: a run claimed by a wave that is held up - a long run, a wait for an item - sits
         // idle, and every later rating of its items waits behind it.
+        // The dequeue is branch-free on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around
+        // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice).
+        // Runs are handed out in stored order and a wave finishes a run before it walks the next one it claimed,
+        // so the earliest unfinished rating is always being walked: ticket waits cannot deadlock.
         auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
         auto index = [&](int32_t jj, RunIdx &x) {
             const int32_t ii = jj < nr ? jj : nr;
@@ -749,58 +794,17 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             jf = claim();
             index(jf, x);
         }
-    } else if (g.user_unique) {
-        // branch-free dequeue on purpose: with `if (lane == 0) atomicAdd` hipcc threads lanes 1..63 around
-        // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice)
-        // Three runs in flight per wave: walking `cur`, head loads of `nxt` issued, index words of `far`
-        // issued.  Runs are handed out in stored order and a wave finishes a run before it walks the next
-        // one it claimed, so the earliest unfinished rating is always being walked: ticket waits cannot
-        // deadlock however far ahead the claims run.
-        // Claims past the end of the block are turned into the grid's sentinel run (an empty run after the
-        // last real one): its loads are issued like any other and never used, so nothing in the loop is
-        // conditional except the walk itself.
-        auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
-        auto real = [&](int32_t jj) { return jj < run_hi ? jj : g.sentinel_run; };
-        // Pipeline per wave: walking run j, head loads (row, bias, rating metadata) of run j+1 in flight,
-        // index words of runs j+2 and j+3 in flight.  The index words are consumed a full iteration after
-        // they were issued, so the counted vmcnt that guards them leaves the younger loads (and the
-        // untracked stores) of the last iteration in flight.
-        RunHead<T, KC> cur, nxt;
-        RunIdx xn, xf, xg;
-        int32_t j = claim();
-        run_index(g, real(j), xn);
-        load_run<T, KC, FAST>(g, xn, P, b_u, z, k, lane, cur);
-        int32_t jn = claim();
-        run_index(g, real(jn), xn);
-#ifndef MFSGD_SHALLOW
-        int32_t jf = claim();
-        run_index(g, real(jf), xf);
-#endif
-        PF_T(b1);
-        PF_ADD(PF_PROLOGUE, b0, b1);
-        while (j < run_hi) {
-            PF_T(i0);
-            load_run<T, KC, FAST>(g, xn, P, b_u, z, k, lane, nxt);
-            const int32_t jg = claim();
-            run_index(g, real(jg), xg);
-            PF_T(i1);
-            PF_ADD(PF_ISSUE, i0, i1);
-            walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                              tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
-            cur = nxt;
-#ifdef MFSGD_SHALLOW
-            xn = xg;
-            j = jn;
-            jn = jg;
-#else
-            xn = xf;
-            xf = xg;
-            j = jn;
-            jn = jf;
-            jf = jg;
-#endif
-        }
-    } else {
+    }
+    if (lo + RT_CAP < run_hi) {   // another chunk follows: its table replaces this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    }   // chunks
+    }   // uniq
+    if (!FAST) {
+    if (!uniq) {
+        ctl[CTL_RUN] = 0;
+        __syncthreads();
         // a user may own several runs of this block: all of them go to one wave, in stored order
         for (int32_t j = run_lo; j < run_hi; ++j) {
             if ((int)(mix32((uint32_t)g.run_user[j]) % (uint32_t)nw) != wave) continue;
@@ -812,6 +816,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
                                                  tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
+    }
     }
     PF_T(b2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
 #endif
-    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), -1};
+    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), (int *)(smem + lp.ring_ui), -1};
     process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
                                        bis, s.err, hot, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
                                        __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
         const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             __builtin_amdgcn_readfirstlane(g.col_hot[c])};
+                             (int *)(smem + lp.ring_ui), __builtin_amdgcn_readfirstlane(g.col_hot[c])};
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -1050,7 +1055,7 @@ enum { CTL_TAIL = 4, CTL_END = 5, CTL_CLAIM = 6 };
 enum { E_ROW = 0, E_NRUNS = 1, E_DONE = 2, E_WORDS = 4 };
 
 struct StreamPlan {  // byte offsets in dynamic LDS (multiples of 16)
-    uint32_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, base, ent, cum, rt_u, rt_t, rowrun, total;
+    uint32_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, ring_ui, base, ent, cum, rt_u, rt_t, rowrun, total;
     int32_t trigger; // the next stripe is looked for once this many 256ths of the newest block's runs are claimed
     int32_t depth;   // user stripes a workgroup may hold at once (1..BQ): rows are scarce when Gr is close to the grid size
 };
@@ -1069,6 +1074,7 @@ StreamPlan stream_plan(int32_t ibp, int32_t Gr, int32_t k)
     p.ring_st = o; o = up(o + (size_t)HOT_R * 4);
     p.ring_s = o; o = up(o + (size_t)HOT_R * 2 * sizeof(T));
     p.ring_p = o; o = up(o + (size_t)HOT_R * k * sizeof(T));
+    p.ring_ui = o; o = up(o + (size_t)HOT_R * 8);
     p.base = o; o = up(o + (size_t)BQ * ibp * 4);
     p.ent = o; o = up(o + (size_t)BQ * E_WORDS * 4);
     p.cum = o; o = up(o + ((size_t)Gr + 1) * 4);
@@ -1135,7 +1141,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_stream(GridView g, T *P, T *Q
         stripe_load<T, true>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             __builtin_amdgcn_readfirstlane(g.col_hot[c])};
+                             (int *)(smem + lp.ring_ui), __builtin_amdgcn_readfirstlane(g.col_hot[c])};
         const int32_t hot_total = __builtin_amdgcn_readfirstlane(g.col_hot_deg[c]);
         if (wave == 0) {
             // ------------------------------------------------------------------ scheduler
@@ -1267,47 +1273,8 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_stream(GridView g, T *P, T *Q
             }
         } else if (wave == nw - 1 && hot.item >= 0) {
             // ------------------------------------------------------------------ server of the most rated item
-            const int32_t hl = hot.item - c_base;
-            T q[KC], zz[KC], rp[KC], bi, rbu, rr;
-            int32_t seen;
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
-            bi = bis[hl];
-            auto fetch = [&](int32_t hs) {
-                seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
-                rbu = hot.s[2 * hs];
-                rr = hot.s[2 * hs + 1];
-            };
-            __builtin_amdgcn_s_setprio(3);
-            fetch(0);
-            for (int32_t t = 0; t < hot_total; ++t) {
-                const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
-                for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
-                    if (spins >= SPIN_TICKET_MAX) { atomicOr(s.err, 1); break; }
-                    if (spins > 4) __builtin_amdgcn_s_sleep(1);
-                    fetch(hs);
-                }
-                T cp[KC], pn[KC];
-#pragma unroll
-                for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
-                T cbu = rbu;
-                const T rest = rr - b - cbu;
-                fetch((t + 1) & (HOT_R - 1));
-                const T e = sgd_step<T, KC>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
-                cbu += alpha * (e - beta1 * cbu);
-#pragma unroll
-                for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
-                *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
-            *sink_ptr(&bis[hl], ctl, lane) = bi;
+            serve_hot<T, KC>(hot, hot_total, hot.item - c_base, qs, bis, k, lane, ctl, b, alpha, beta1, beta2, variant, P,
+                             b_u, s.err, false PF_PASS);
         } else {
             // ------------------------------------------------------------------ worker
             auto claim = [&](bool take) {
@@ -1428,7 +1395,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         }
         return MFSGD_OK;
     }
-    const bool fast = k == 64 * KC && z == nullptr;
+    const bool fast = k == 64 * KC && z == nullptr && gv.user_unique;
     auto kern = fast ? k_epoch_free<T, KC, STAGE, true> : k_epoch_free<T, KC, STAGE, false>;
     const char *dbg_env = getenv("MFSGD_DEBUG_FLAGS");
     const int32_t dbg = dbg_env ? atoi(dbg_env) : 0;

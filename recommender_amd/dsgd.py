@@ -67,12 +67,21 @@ def ring_epoch(plan, rank, Q, b_i, compute, dist=None):
         nq = plan.shard_at(rank, s + 1)
         a0, a1 = plan.item_range(q)
         r0, r1 = plan.item_range(nq)
-        ops = [dist.P2POp(dist.isend, Q[a0:a1], plan.send_to(rank)),
-               dist.P2POp(dist.isend, b_i[a0:a1], plan.send_to(rank)),
-               dist.P2POp(dist.irecv, Q[r0:r1], plan.recv_from(rank)),
-               dist.P2POp(dist.irecv, b_i[r0:r1], plan.recv_from(rank))]
+        staged = getattr(Q, "is_cuda", False) and dist.get_backend() == "gloo"
+        if staged:   # rehearsal on one GPU box: gloo moves host buffers only (RCCL sends the device rows in place)
+            sq, sb = Q[a0:a1].cpu(), b_i[a0:a1].cpu()
+            rq, rb = Q[r0:r1].cpu(), b_i[r0:r1].cpu()
+        else:
+            sq, sb, rq, rb = Q[a0:a1], b_i[a0:a1], Q[r0:r1], b_i[r0:r1]
+        ops = [dist.P2POp(dist.isend, sq, plan.send_to(rank)),
+               dist.P2POp(dist.isend, sb, plan.send_to(rank)),
+               dist.P2POp(dist.irecv, rq, plan.recv_from(rank)),
+               dist.P2POp(dist.irecv, rb, plan.recv_from(rank))]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        if staged:
+            Q[r0:r1].copy_(rq)
+            b_i[r0:r1].copy_(rb)
 
 
 def gather_items(plan, rank, Q, b_i, dist):
@@ -87,9 +96,9 @@ def gather_items(plan, rank, Q, b_i, dist):
 def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4):
     """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~64+ ratings, with
     up to 256 column stripes per shard (one workgroup each) and twice as many row stripes as columns."""
-    ibp_max = max(1, (144 * 1024) // ((k + 1) * esz + 4))
+    ibp_max = max(1, (120 * 1024) // ((k + 1) * esz + 4))
     cols = min(256, max(1, n_items // world))
-    rows = min(2 * cols, max(1, n_users // world))
+    rows = min(cols + cols // 4, max(1, n_users // world))
     per = n_train / float(world * world)
     want = max(1.0, per / 64.0)
     if rows * cols > want:
