@@ -247,6 +247,7 @@ def _synthetic(rng, U, I, n, lead=False):
     (128, 3000, 900, 200000, (64, 16), 8),
     (64, 2000, 5000, 150000, (32, 32), 16),
     (200, 700, 400, 40000, (16, 8), 8),
+    (64, 3000, 600, 120000, (4, 12), 16),      # 750 users per stripe: blocks longer than the LDS run table (chunks)
 ])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
 def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode):
@@ -294,6 +295,14 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
             orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z)
     for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
         assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= 1e-4, name
+
+
+def test_streaming_kernel_replays_on_oracle(ra, orc, monkeypatch):
+    """The experimental barrier-free kernel (MFSGD_STREAM=1) must meet the same bar as the default one."""
+    monkeypatch.setenv("MFSGD_STREAM", "1")
+    monkeypatch.setenv("MFSGD_STREAM_DEPTH", "2")
+    test_free_block_schedule_replays_on_oracle(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none")
+    test_free_block_schedule_replays_on_oracle(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none")
 
 
 def test_throughput_mode_rmse_close_to_deterministic(ra):
