@@ -26,8 +26,8 @@ void mfsgd_set_error(const char *fmt, ...);
 
 #define MF_LAUNCH_CHECK() MF_HIP(hipGetLastError())
 
-// ---- wave64 sum.  f32: DPP butterfly inside each 16-lane row, then two permlane swaps; the tree is fixed,
-// so the result is the same on every run and in every lane.
+// ---- wave64 sum.  f32: DPP butterfly inside each 16-lane row, two row broadcasts (gfx9-family DPP), and one
+// readlane: the total comes back wave-uniform (an SGPR), the tree is fixed, so the result is the same on every run.
 __device__ __forceinline__ float wave_sum(float v)
 {
     int x;
@@ -39,12 +39,12 @@ __device__ __forceinline__ float wave_sum(float v)
     v += __int_as_float(x);
     x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); // row_mirror
     v += __int_as_float(x);
-    // every lane of a 16-lane row now holds its row's sum; two gfx950 lane swaps fold the four rows without
-    // leaving the VALU (no readlane / SALU hop): rows (0,1),(2,3) first, then the two halves of the wave
-    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
-    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    // every lane of a 16-lane row now holds its row's sum
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); // row_bcast15 -> rows 1,3
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); // row_bcast31 -> rows 2,3
+    v += __int_as_float(x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));        // (r0+r1)+(r2+r3)
 }
 
 __device__ __forceinline__ double wave_sum(double v)
