@@ -96,6 +96,11 @@ int mfsgd_hip_bucket(const int32_t *samples, int64_t n, int32_t stride, int32_t 
 int mfsgd_hip_csr_from_coo(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users,
                            int64_t *row_ptrs, int32_t *col_inds, void *stream);
 
+/* renumber_column: Recommender.renumber_column (Recommender.py:18-25), the ingestion step that turns raw ids
+ * (any int64) into dense ones: out_ids[t] = rank of values[t] among the sorted distinct values; the number of
+ * distinct values goes to *h_n_unique (host).  Synchronises. */
+int mfsgd_hip_renumber_column(const int64_t *values, int64_t n, int32_t *out_ids, int64_t *h_n_unique, void *stream);
+
 /* ---- the block grid + on-GPU scheduler + epoch kernel: replaces the scheduler actor
  * (RayBlockScheduler.py:14-116), the worker loop (:148-181), make_subsample/update_params
  * (SGDRecommender.py:88-121) and the per-block kernel calls.  A grid holds the ratings bucketed into

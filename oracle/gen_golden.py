@@ -383,6 +383,22 @@ def main():
                    test_rmse=exact_rmse(m.test_samples, rp, ci, m.P, m.Q, m.b_u, m.b_i, m.b, m.y))
         np.savez_compressed(os.path.join(OUT, "real_ml_small_20k.npz"), **res)
         print("real data 20k rows: train/test rmse = %.4f / %.4f" % (res["train_rmse"], res["test_rmse"]))
+
+    # ---------------------------------------------------------------- ingestion: Recommender.renumber_column
+    # (Recommender.py:18-25) on the first 5000 rows of the real file (sparse 64-bit-ish ids) and on signed ids
+    import Recommender as refrec
+    head = df.iloc[:5000][["userId", "movieId", "rating"]].copy()
+    ren = refrec.Recommender.renumber_column(head.copy(), "userId")
+    ren = refrec.Recommender.renumber_column(ren, "movieId")
+    rng = np.random.default_rng(99)
+    odd = pd.DataFrame({"a": rng.integers(-2**40, 2**40, size=3000) // 7 * 7, "b": rng.integers(0, 50, size=3000)})
+    odd_r = refrec.Recommender.renumber_column(odd.copy(), "a")
+    np.savez_compressed(os.path.join(OUT, "renumber.npz"),
+                        user_raw=head["userId"].to_numpy(np.int64), item_raw=head["movieId"].to_numpy(np.int64),
+                        rating_raw=head["rating"].to_numpy(np.float64),
+                        user_new=ren["userId"].to_numpy(np.int64), item_new=ren["movieId"].to_numpy(np.int64),
+                        odd_raw=odd["a"].to_numpy(np.int64), odd_new=odd_r["a"].to_numpy(np.int64))
+    print("renumber_column: %d users, %d items in 5000 rows" % (ren["userId"].max() + 1, ren["movieId"].max() + 1))
     return 0
 
 

@@ -197,3 +197,27 @@ void orc_bold_driver(double train_rmse, double *alpha, double *previous)
 #include "mf_oracle_impl.h"
 #undef T
 #undef SUF
+
+/* Recommender.renumber_column (Recommender.py:18-25): all_values = unique(), sort, value -> position. */
+static int cmp_i64(const void *a, const void *b)
+{
+    const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+int64_t orc_renumber_column(const int64_t *values, int64_t n, int32_t *out)
+{
+    if (n <= 0) return 0;
+    int64_t *u = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+    memcpy(u, values, (size_t)n * sizeof(int64_t));
+    qsort(u, (size_t)n, sizeof(int64_t), cmp_i64);
+    int64_t m = 0;
+    for (int64_t t = 0; t < n; ++t)
+        if (t == 0 || u[t] != u[t - 1]) u[m++] = u[t];
+    for (int64_t t = 0; t < n; ++t) {
+        int64_t lo = 0, hi = m;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (u[mid] < values[t]) lo = mid + 1; else hi = mid; }
+        out[t] = (int32_t)lo;
+    }
+    free(u);
+    return m;
+}

@@ -124,6 +124,14 @@ def csr_from_coo(samples, n_users):
     return rp, ci
 
 
+def renumber_column(values):
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.empty(len(values), dtype=np.int32)
+    lib().orc_renumber_column.restype = C.c_int64
+    m = lib().orc_renumber_column(_p(values), C.c_int64(len(values)), _p(out))
+    return out, int(m)
+
+
 def bold_driver(train_rmse, alpha, previous):
     a, p = C.c_double(alpha), C.c_double(previous)
     lib().orc_bold_driver(C.c_double(train_rmse), C.byref(a), C.byref(p))

@@ -54,6 +54,42 @@ class Recommender:
         return self._d_rowptrs, self._d_colinds
 
     # --- reference API -----------------------------------------------------------------------
+    @staticmethod
+    def renumber_ids(values):
+        """Dense ids for a column of raw ids on the device: value -> rank among the sorted distinct values
+        (what Recommender.renumber_column does with a dict, Recommender.py:18-25).  Returns (ids int32, n_unique)."""
+        _abi.require_gpu()
+        torch = _abi.torch_mod()
+        v = np.ascontiguousarray(np.asarray(values), dtype=np.int64)
+        d_v = torch.from_numpy(v).cuda()
+        out = torch.empty(max(len(v), 1), dtype=torch.int32, device="cuda")[:len(v)]
+        m = _abi.c_i64(0)
+        _abi.check(_abi.lib().mfsgd_hip_renumber_column(_abi.ptr(d_v), len(v), _abi.ptr(out), _abi.C.byref(m),
+                                                        _abi.stream_ptr()))
+        return out.cpu().numpy(), int(m.value)
+
+    @staticmethod
+    def renumber_column(df, column):
+        """Recommender.renumber_column (Recommender.py:18-25): same call shape - a pandas DataFrame and a column
+        name, the column is replaced by dense ids and the frame returned.  Integer ids only (the reference's SQL
+        path also feeds strings; that path is out of scope)."""
+        ids, _ = Recommender.renumber_ids(df[column].to_numpy())
+        df[column] = ids.astype(np.int64)
+        return df
+
+    def load_samples_from_csv(self, path, n="all", columns=("userId", "movieId", "rating")):
+        """a ratings file such as the reference's NCF/ratings.csv -> dense ids -> the same
+        (n,3) int32 array load_samples_from_npy takes (ratings truncate to int like Recommender.py:54), then the
+        holdout split and CSR of load_samples_from_array."""
+        import pandas as pd
+        df = pd.read_csv(path, usecols=list(columns))
+        if n != "all":
+            df = df.iloc[:n]
+        u, _ = Recommender.renumber_ids(df[columns[0]].to_numpy())
+        i, _ = Recommender.renumber_ids(df[columns[1]].to_numpy())
+        a = np.column_stack([u, i, df[columns[2]].to_numpy()]).astype(np.int32)
+        self.load_samples_from_array(a, "all")
+
     def load_samples_from_npy(self, path, n):
         """Recommender.py:50-65: np.load -> int32 (ratings truncate) -> first n rows -> n_users/n_items =
         max id + 1 -> random 10 % hold-out (np.random.choice, legacy global RNG) -> train CSR."""

@@ -154,6 +154,20 @@ int sort_pairs(uint32_t *k_in, uint32_t *k_out, int64_t *v_in, int64_t *v_out, i
     return MFSGD_OK;
 }
 
+__global__ void k_rank_of(const int64_t *__restrict__ values, int64_t n, const int64_t *__restrict__ uniq,
+                          const int64_t *__restrict__ n_uniq, int32_t *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t v = values[t];
+    int64_t lo = 0, hi = *n_uniq;   // first position with uniq[pos] >= v; v is present
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (uniq[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[t] = (int32_t)lo;
+}
+
 }  // namespace mfprep
 
 using namespace mfprep;
@@ -281,6 +295,33 @@ extern "C" int mfsgd_hip_csr_from_coo(const int32_t *samples, int64_t n, int32_t
     MF_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gather_cols, dim3(nblk(n)), dim3(256), 0, st, samples, stride, v1.as<int64_t>(), n, col_inds);
     MF_LAUNCH_CHECK();
+    MF_HIP(hipStreamSynchronize(st));
+    return MFSGD_OK;
+}
+
+// Recommender.renumber_column (Recommender.py:18-25): every value -> its rank among the sorted distinct values.
+extern "C" int mfsgd_hip_renumber_column(const int64_t *values, int64_t n, int32_t *out_ids, int64_t *h_n_unique,
+                                         void *stream)
+{
+    MF_ARG(n >= 0 && h_n_unique && (n == 0 || (values && out_ids)), "renumber_column: bad argument");
+    MF_ARG(n < ((int64_t)1 << 31), "renumber_column: n=%lld does not fit int32", (long long)n);
+    *h_n_unique = 0;
+    if (n == 0) return MFSGD_OK;
+    hipStream_t st = as_stream(stream);
+    DevBuf sorted, uniq, cnt, tmp;
+    MF_HIP(sorted.alloc((size_t)n * 8)); MF_HIP(uniq.alloc((size_t)n * 8)); MF_HIP(cnt.alloc(8));
+    size_t tb = 0;
+    MF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, values, sorted.as<int64_t>(), (int)n, 0, 64, st));
+    MF_HIP(tmp.alloc(tb));
+    MF_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, values, sorted.as<int64_t>(), (int)n, 0, 64, st));
+    size_t tb2 = 0;
+    DevBuf tmp2;
+    MF_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted.as<int64_t>(), uniq.as<int64_t>(), cnt.as<int64_t>(), (int)n, st));
+    MF_HIP(tmp2.alloc(tb2));
+    MF_HIP(hipcub::DeviceSelect::Unique(tmp2.p, tb2, sorted.as<int64_t>(), uniq.as<int64_t>(), cnt.as<int64_t>(), (int)n, st));
+    hipLaunchKernelGGL(k_rank_of, dim3(nblk(n)), dim3(256), 0, st, values, n, uniq.as<int64_t>(), cnt.as<int64_t>(), out_ids);
+    MF_LAUNCH_CHECK();
+    MF_HIP(hipMemcpyAsync(h_n_unique, cnt.p, 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     return MFSGD_OK;
 }

@@ -399,3 +399,25 @@ def test_consumer_loop_matches_golden_full_mode(ra):
     for name, ref in (("P", P), ("Q", Q), ("y", y), ("b_u", bu), ("b_i", bi)):
         assert relerr(getattr(m, name), ref) <= 1e-9, name
     assert m.alpha == pytest.approx(0.006 * 1.06)
+
+
+def test_renumber_column_and_csv_ingestion(ra, tmp_path):
+    """raw ids -> dense ids on the device, bit-exact with the reference's renumber_column."""
+    import pandas as pd
+    g = load("renumber.npz")
+    for raw, new in (("user_raw", "user_new"), ("item_raw", "item_new"), ("odd_raw", "odd_new")):
+        ids, m = ra.Recommender.renumber_ids(g[raw])
+        assert np.array_equal(ids.astype(np.int64), g[new]) and m == int(g[new].max()) + 1
+    df = pd.DataFrame({"userId": g["user_raw"], "movieId": g["item_raw"], "rating": g["rating_raw"]})
+    out = ra.Recommender.renumber_column(df.copy(), "userId")
+    assert np.array_equal(out["userId"].to_numpy(), g["user_new"])
+    path = tmp_path / "ratings.csv"
+    df.to_csv(path, index=False)
+    m = ra.ExplicitMF(n_threads=3, n_factors=8, verbose=False)
+    np.random.seed(7)
+    m.load_samples_from_csv(str(path))
+    assert m.n_users == int(g["user_new"].max()) + 1 and m.n_items == int(g["item_new"].max()) + 1
+    assert len(m.samples) + len(m.test_samples) == len(df) and len(m.test_samples) == len(df) // 10
+    both = np.concatenate([m.samples, m.test_samples])
+    ref = np.column_stack([g["user_new"], g["item_new"], g["rating_raw"]]).astype(np.int32)
+    assert np.array_equal(both[np.lexsort(both.T[::-1])], ref[np.lexsort(ref.T[::-1])])

@@ -203,3 +203,10 @@ def test_bold_driver_g9():
     assert a == pytest.approx(0.006 * 1.06) and p == pytest.approx(1.0 - 1e-4)
     a, p = orc.bold_driver(1.1, a, p)
     assert a == pytest.approx(0.006 * 1.06 * 0.6)
+
+
+def test_renumber_column_vs_reference():
+    g = load("renumber.npz")
+    for raw, new in (("user_raw", "user_new"), ("item_raw", "item_new"), ("odd_raw", "odd_new")):
+        ids, m = orc.renumber_column(g[raw])
+        assert np.array_equal(ids.astype(np.int64), g[new]) and m == int(g[new].max()) + 1
