@@ -315,7 +315,10 @@ constexpr int RT_CAP = 512;   // runs per block the LDS run table takes
 // Slot state word: 3g = free for generation g = ticket / HOT_R, 3g+1 = request posted, 3g+2 = answered.
 // When the item's rating is the LAST of the user's run (most runs have one rating) the worker does not wait:
 // the server itself stores the new user row and bias to HBM and frees the slot, the worker moves on.
-constexpr int HOT_R = 16;   // >= waves per workgroup: a worker has at most one request posted
+#ifndef MFSGD_HOT_R
+#define MFSGD_HOT_R 16
+#endif
+constexpr int HOT_R = MFSGD_HOT_R;   // slots of the request ring (a power of two)
 template <typename T> struct HotRing {
     int *st;       // [HOT_R]
     T *s;          // [HOT_R][2]  {b_u, rating}
@@ -1722,7 +1725,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         G->info.user_unique = hd ? 0 : 1;
     }
     // 5b. the item of every stripe whose chain gets a server wave, and how often it occurs in each block
-    if (G->info.user_unique) {
+    // Experimental (MFSGD_SERVE_HOT=1): measured slower than the LDS tickets it replaces.
+    if (G->info.user_unique && getenv("MFSGD_SERVE_HOT")) {
         DevBuf deg;
         MF_HIP(deg.alloc((size_t)n_items * 4));
         MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));

@@ -264,7 +264,10 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
     d_s = torch.from_numpy(s).cuda()
     gr = Grid(d_s, U, I, ubp, ibp, order=1)
     assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
-    assert gr.info.n_served > 0 or k not in (64, 128)   # the server-wave path runs in the k=64,128 "none" cases
+    if os.environ.get("MFSGD_SERVE_HOT"):
+        assert gr.info.n_served > 0 or k not in (64, 128)   # the server-wave path runs in the k=64,128 "none" cases
+    else:
+        assert gr.info.n_served == 0
     P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
     Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
     y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
@@ -297,10 +300,19 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
         assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= 1e-4, name
 
 
+def test_server_wave_replays_on_oracle(ra, orc, monkeypatch):
+    """The experimental server wave (MFSGD_SERVE_HOT=1: a stripe's most rated item kept in one wave's registers)
+    must meet the same bar as the LDS tickets it would replace."""
+    monkeypatch.setenv("MFSGD_SERVE_HOT", "1")
+    test_free_block_schedule_replays_on_oracle(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none")
+    test_free_block_schedule_replays_on_oracle(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none")
+
+
 def test_streaming_kernel_replays_on_oracle(ra, orc, monkeypatch):
     """The experimental barrier-free kernel (MFSGD_STREAM=1) must meet the same bar as the default one."""
     monkeypatch.setenv("MFSGD_STREAM", "1")
     monkeypatch.setenv("MFSGD_STREAM_DEPTH", "2")
+    monkeypatch.setenv("MFSGD_SERVE_HOT", "1")
     test_free_block_schedule_replays_on_oracle(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none")
     test_free_block_schedule_replays_on_oracle(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none")
 
