@@ -101,6 +101,17 @@ int mfsgd_hip_csr_from_coo(const int32_t *samples, int64_t n, int32_t stride, in
  * distinct values goes to *h_n_unique (host).  Synchronises. */
 int mfsgd_hip_renumber_column(const int64_t *values, int64_t n, int32_t *out_ids, int64_t *h_n_unique, void *stream);
 
+/* ---- batched scoring + top-N: the dense contraction of ExplicitMF.predict (SGDRecommender.py:82-83,
+ * user_vecs[row,:].dot(item_vecs[col,:].T)) fused with the selection of the `topn` best items per user, so the
+ * users x items score matrix is never stored.  score(u,i) = P[u].Q[i], plus b_u[u] + b_i[i] + b when with_bias
+ * (the training predictor numba_methods.py:17 without the implicit term).  users[n_batch] are row ids of P;
+ * out_items / out_scores are [n_batch][topn], best first, ties to the lower item id; topn in {4, 8, 16};
+ * 32 <= k <= 200 (the user tiles and item chunks of a workgroup share the 160 KB of LDS).  Matrix-core (MFMA
+ * fp32) kernel; asynchronous on `stream`. */
+int mfsgd_hip_topn_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
+                       const int32_t *users, int64_t n_batch, int64_t n_items, int32_t k, int32_t with_bias,
+                       int32_t topn, int32_t *out_items, float *out_scores, void *stream);
+
 /* ---- the block grid + on-GPU scheduler + epoch kernel: replaces the scheduler actor
  * (RayBlockScheduler.py:14-116), the worker loop (:148-181), make_subsample/update_params
  * (SGDRecommender.py:88-121) and the per-block kernel calls.  A grid holds the ratings bucketed into

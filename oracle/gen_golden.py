@@ -399,6 +399,18 @@ def main():
                         user_new=ren["userId"].to_numpy(np.int64), item_new=ren["movieId"].to_numpy(np.int64),
                         odd_raw=odd["a"].to_numpy(np.int64), odd_new=odd_r["a"].to_numpy(np.int64))
     print("renumber_column: %d users, %d items in 5000 rows" % (ren["userId"].max() + 1, ren["movieId"].max() + 1))
+
+    # ---------------------------------------------------------------- scoring: ExplicitMF.predict (SGDRecommender.py:82-83)
+    rng = np.random.default_rng(4242)
+    Pp = rng.normal(scale=0.3, size=(70, 64)).astype(np.float32)
+    Qq = rng.normal(scale=0.3, size=(333, 64)).astype(np.float32)
+    Qq[17] = Qq[5]                                     # an exact tie: the lower item id must come first
+    us = rng.permutation(70)[:45].astype(np.int32)
+    dense = sg.ExplicitMF.predict(us, np.arange(333), Pp.astype(np.float64), Qq.astype(np.float64))   # (45, 333)
+    order = np.argsort(-dense, axis=1, kind="stable")[:, :16]
+    np.savez_compressed(os.path.join(OUT, "topn.npz"), P=Pp, Q=Qq, users=us, items=order.astype(np.int32),
+                        scores=np.take_along_axis(dense, order, axis=1))
+    print("predict/top-16: %d users x %d items" % dense.shape)
     return 0
 
 

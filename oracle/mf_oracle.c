@@ -221,3 +221,30 @@ int64_t orc_renumber_column(const int64_t *values, int64_t n, int32_t *out)
     free(u);
     return m;
 }
+
+/* Top-N of ExplicitMF.predict (SGDRecommender.py:82-83): scores[u][i] = P[u].Q[i] (+ b_u[u] + b_i[i] + b), the N
+ * best items per user, best first, ties to the lower item id (a stable argsort of the negated scores).
+ * float32 factors, float64 accumulation. */
+void orc_topn(const float *P, const float *Q, const float *b_u, const float *b_i, double b, const int32_t *users,
+              int64_t n_batch, int64_t n_items, int32_t k, int32_t with_bias, int32_t topn, int32_t *out_items,
+              double *out_scores)
+{
+    double *sc = (double *)malloc((size_t)n_items * sizeof(double));
+    for (int64_t m = 0; m < n_batch; ++m) {
+        const float *p = P + (int64_t)users[m] * k;
+        for (int64_t i = 0; i < n_items; ++i) {
+            double acc = 0.0;
+            for (int f = 0; f < k; ++f) acc += (double)p[f] * (double)Q[i * k + f];
+            sc[i] = with_bias ? acc + (double)b_u[users[m]] + (double)b_i[i] + b : acc;
+        }
+        for (int j = 0; j < topn; ++j) {   /* selection: N passes, first maximum wins (lowest id on ties) */
+            int64_t best = -1;
+            for (int64_t i = 0; i < n_items; ++i)
+                if (sc[i] == sc[i] && (best < 0 || sc[i] > sc[best])) best = i;
+            out_items[m * topn + j] = (int32_t)best;
+            out_scores[m * topn + j] = best >= 0 ? sc[best] : 0.0;
+            if (best >= 0) sc[best] = 0.0 / 0.0;   /* taken */
+        }
+    }
+    free(sc);
+}

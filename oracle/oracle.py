@@ -132,6 +132,20 @@ def renumber_column(values):
     return out, int(m)
 
 
+def topn(P, Q, users, n, b_u=None, b_i=None, b=0.0):
+    P = np.ascontiguousarray(P, dtype=np.float32); Q = np.ascontiguousarray(Q, dtype=np.float32)
+    users = np.ascontiguousarray(users, dtype=np.int32)
+    wb = b_u is not None and b_i is not None
+    bu = np.ascontiguousarray(b_u, dtype=np.float32) if wb else np.zeros(1, np.float32)
+    bi = np.ascontiguousarray(b_i, dtype=np.float32) if wb else np.zeros(1, np.float32)
+    items = np.empty((len(users), n), dtype=np.int32)
+    scores = np.empty((len(users), n), dtype=np.float64)
+    lib().orc_topn(_p(P), _p(Q), _p(bu), _p(bi), C.c_double(b), _p(users), C.c_int64(len(users)),
+                   C.c_int64(Q.shape[0]), C.c_int32(P.shape[1]), C.c_int32(1 if wb else 0), C.c_int32(n),
+                   _p(items), _p(scores))
+    return items, scores
+
+
 def bold_driver(train_rmse, alpha, previous):
     a, p = C.c_double(alpha), C.c_double(previous)
     lib().orc_bold_driver(C.c_double(train_rmse), C.byref(a), C.byref(p))

@@ -342,6 +342,41 @@ class ExplicitMF(Recommender):
         """SGDRecommender.py:82-83: plain dot of factor rows (no biases, no implicit term)."""
         return user_vecs[row, :].dot(item_vecs[col, :].T)
 
+    @staticmethod
+    def top_n(users, user_vecs, item_vecs, n=10, b_u=None, b_i=None, b=0.0):
+        """The `n` best items for each of `users`: what `argsort(-predict(users, all_items, ...))[:, :n]` gives,
+        without ever forming the users x items matrix (mfsgd_hip_topn_f32: MFMA tiles + top-n on the fly).
+        With b_u/b_i the scores are the training predictor's (numba_methods.py:17, no implicit term), else the
+        plain dot of `predict`.  Arrays may be NumPy or ROCm tensors; returns (items [len(users)][n] int32,
+        scores [len(users)][n] float32), best first, ties to the lower item id."""
+        _abi.require_gpu()
+        torch = _abi.torch_mod()
+        if not 1 <= n <= 16:
+            raise ValueError("top_n: n must be in [1, 16]")
+        nn = 4 if n <= 4 else (8 if n <= 8 else 16)
+        dP, dQ = _abi.to_device(user_vecs, "float32"), _abi.to_device(item_vecs, "float32")
+        if int(dP.shape[1]) != int(dQ.shape[1]) or not 32 <= int(dP.shape[1]) <= 200:
+            raise ValueError("top_n: factor matrices must share k in [32, 200]")
+        with_bias = b_u is not None and b_i is not None
+        dbu = _abi.to_device(b_u, "float32") if with_bias else None
+        dbi = _abi.to_device(b_i, "float32") if with_bias else None
+        du = _abi.to_device(np.asarray(users).reshape(-1) if not hasattr(users, "is_cuda") else users, "int32")
+        m = int(du.shape[0])
+        if m and (int(du.min()) < 0 or int(du.max()) >= int(dP.shape[0])):
+            raise IndexError("top_n: a user id is outside the factor matrix")
+        items = torch.empty((m, nn), dtype=torch.int32, device="cuda")
+        scores = torch.empty((m, nn), dtype=torch.float32, device="cuda")
+        _abi.check(_abi.lib().mfsgd_hip_topn_f32(_abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi), float(b),
+                                                 _abi.ptr(du), m, int(dQ.shape[0]), int(dP.shape[1]),
+                                                 1 if with_bias else 0, nn, _abi.ptr(items), _abi.ptr(scores),
+                                                 _abi.stream_ptr()))
+        torch.cuda.synchronize()
+        return items[:, :n].cpu().numpy(), scores[:, :n].cpu().numpy()
+
+    def recommend(self, users, n=10):
+        """Top-n items (current id space) for `users` under the trained model's predictor without the implicit term."""
+        return ExplicitMF.top_n(users, self.P, self.Q, n, self.b_u, self.b_i, self.b)
+
     def predict_rating(self, user, item):
         """The training predictor (numba_methods.py:17) for one (user, item) in the current id space."""
         rp, ci = self.ratings.rowptrs, self.ratings.colinds

@@ -433,3 +433,38 @@ def test_renumber_column_and_csv_ingestion(ra, tmp_path):
     both = np.concatenate([m.samples, m.test_samples])
     ref = np.column_stack([g["user_new"], g["item_new"], g["rating_raw"]]).astype(np.int32)
     assert np.array_equal(both[np.lexsort(both.T[::-1])], ref[np.lexsort(ref.T[::-1])])
+
+
+def _check_topn(items, scores, ref_items, ref_scores, tol):
+    """GPU fp32 scores against the float64 oracle: scores to `tol`; item ids equal wherever the oracle's gap to the
+    neighbouring scores is larger than the fp32 noise (near-ties may swap)."""
+    assert items.shape == ref_items.shape
+    assert np.allclose(scores, ref_scores, rtol=tol, atol=tol)
+    gap = np.full(ref_scores.shape, np.inf)
+    d = np.abs(np.diff(ref_scores, axis=1))
+    gap[:, :-1] = np.minimum(gap[:, :-1], d); gap[:, 1:] = np.minimum(gap[:, 1:], d)
+    clear = gap > 10 * tol * np.maximum(1.0, np.abs(ref_scores))
+    clear[:, -1] = False      # the last place may trade with the first item left out
+    assert np.array_equal(items[clear], ref_items[clear])
+    assert (np.diff(scores, axis=1) <= 1e-6).all()
+
+
+def test_topn_vs_reference_predict_and_oracle(ra, orc):
+    """batched scoring + top-N (MFMA kernel) against the reference's predict (golden) and the oracle."""
+    g = load("topn.npz")
+    for n in (16, 10, 4, 1):
+        items, scores = ra.ExplicitMF.top_n(g["users"], g["P"], g["Q"], n)
+        _check_topn(items, scores, g["items"][:, :n], g["scores"][:, :n], 1e-5)
+        assert np.array_equal(items[:, 0][g["items"][:, 0] == 5], np.full((g["items"][:, 0] == 5).sum(), 5))
+    rng = np.random.default_rng(11)
+    for U, I, k, m in ((300, 1000, 128, 257), (50, 33, 32, 50), (1000, 4097, 200, 130)):
+        P = rng.normal(scale=0.2, size=(U, k)).astype(np.float32); Q = rng.normal(scale=0.2, size=(I, k)).astype(np.float32)
+        bu = rng.normal(size=U).astype(np.float32); bi = rng.normal(size=I).astype(np.float32)
+        users = rng.integers(0, U, size=m).astype(np.int32)
+        ri, rs = orc.topn(P, Q, users, 8, bu, bi, 3.25)
+        items, scores = ra.ExplicitMF.top_n(users, P, Q, 8, bu, bi, 3.25)
+        _check_topn(items, scores, ri, rs, 2e-5)
+    with pytest.raises(ValueError):
+        ra.ExplicitMF.top_n([0], np.zeros((4, 8), np.float32), np.zeros((4, 8), np.float32), 4)
+    with pytest.raises(IndexError):
+        ra.ExplicitMF.top_n([9], g["P"][:5], g["Q"], 4)

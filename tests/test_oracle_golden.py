@@ -210,3 +210,10 @@ def test_renumber_column_vs_reference():
     for raw, new in (("user_raw", "user_new"), ("item_raw", "item_new"), ("odd_raw", "odd_new")):
         ids, m = orc.renumber_column(g[raw])
         assert np.array_equal(ids.astype(np.int64), g[new]) and m == int(g[new].max()) + 1
+
+
+def test_topn_vs_reference_predict():
+    g = load("topn.npz")
+    items, scores = orc.topn(g["P"], g["Q"], g["users"], 16)
+    assert np.array_equal(items, g["items"])
+    assert np.allclose(scores, g["scores"], rtol=0, atol=1e-12)
