@@ -61,42 +61,89 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
         if (u0 + r < n_batch && f < k) v = P[(int64_t)users[u0 + r] * k + f];
         pt[r * ld + f] = v;
     }
-    auto stage = [&](int64_t c, int buf) {   // chunk c of Q -> LDS, all 256 threads
-        float *dst = qc + (size_t)buf * TN_TILE * ld;
+    // A chunk of Q goes HBM -> registers before the multiply of the previous chunk and registers -> LDS after it,
+    // so the load latency hides behind the MFMA loop (one wave per SIMD: nothing else would hide it).
+    constexpr int STG = (TN_TILE * 208 + TN_WAVES * 64 - 1) / (TN_WAVES * 64);   // floats per thread at kpad = 208
+    float stg[STG];
+    float stg_b = 0.f;
+    int32_t src_off[STG], dst_off[STG];   // where this thread's elements of a chunk come from and go to (-1: none)
+#pragma unroll
+    for (int t = 0; t < STG; ++t) {
+        const int e = tid + t * TN_WAVES * 64;
+        const int r = e / kpad, f = e - r * kpad;
+        const bool in = e < TN_TILE * kpad;
+        dst_off[t] = in ? r * ld + f : -1;
+        src_off[t] = in && f < k ? r * k + f : -1;
+    }
+    auto fetch = [&](int64_t c) {
         const int64_t i0 = c * TN_TILE;
-        for (int e = tid; e < TN_TILE * kpad; e += TN_WAVES * 64) {
-            const int r = e / kpad, f = e - r * kpad;
-            float v = 0.f;
-            if (i0 + r < n_items && f < k) v = Q[(i0 + r) * k + f];
-            dst[r * ld + f] = v;
-        }
-        if (tid < TN_TILE) bc[buf * TN_TILE + tid] = (with_bias && i0 + tid < n_items) ? b_i[i0 + tid] : 0.f;
+        const float *src = Q + i0 * k;
+        const int32_t lim = (int32_t)std::min<int64_t>(TN_TILE, n_items - i0) * k;   // rows beyond the last item read as 0
+#pragma unroll
+        for (int t = 0; t < STG; ++t) stg[t] = (src_off[t] >= 0 && src_off[t] < lim) ? src[src_off[t]] : 0.f;
+        if (tid < TN_TILE) stg_b = (with_bias && i0 + tid < n_items) ? b_i[i0 + tid] : 0.f;
+    };
+    auto commit = [&](int buf) {
+        float *dst = qc + (size_t)buf * TN_TILE * ld;
+#pragma unroll
+        for (int t = 0; t < STG; ++t)
+            if (dst_off[t] >= 0) dst[dst_off[t]] = stg[t];
+        if (tid < TN_TILE) bc[buf * TN_TILE + tid] = stg_b;
     };
     float sc[N];
     int32_t id[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) { sc[j] = -INFINITY; id[j] = 0x7fffffff; }
     const int64_t n_chunks = (n_items + TN_TILE - 1) / TN_TILE;
-    stage(0, 0);
+    fetch(0);
+    commit(0);
     __syncthreads();
     const int col = lane & 31, kh = lane >> 5;          // MFMA operand coordinates of this lane
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int buf = (int)(c & 1);
-        if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);    // next chunk lands while this one is multiplied
+        if (c + 1 < n_chunks) fetch(c + 1);             // in flight during the multiply
         const float *qa = qc + (size_t)buf * TN_TILE * ld + col * ld + kh;   // A[item = col][kk + kh]
         const float *pb = pt + col * ld + kh;                               // B[kk + kh][user = col]
         f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int kk = 0; kk < kpad; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], pb[kk], acc, 0, 0, 0);
+        // kpad is a multiple of 8 (zero columns beyond k); the operands of the next four MFMAs are read from LDS
+        // while the current four run (one wave per SIMD: nothing else hides the LDS latency)
+        float a0 = qa[0], a1 = qa[2], a2 = qa[4], a3 = qa[6];
+        float p0 = pb[0], p1 = pb[2], p2 = pb[4], p3 = pb[6];
+        for (int kk = 8; kk < kpad; kk += 8) {
+            const float n0 = qa[kk], n1 = qa[kk + 2], n2 = qa[kk + 4], n3 = qa[kk + 6];
+            const float m0 = pb[kk], m1 = pb[kk + 2], m2 = pb[kk + 4], m3 = pb[kk + 6];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, p2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, p3, acc, 0, 0, 0);
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            p0 = m0; p1 = m1; p2 = m2; p3 = m3;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, p2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, p3, acc, 0, 0, 0);
+        if (c + 1 < n_chunks) commit(buf ^ 1);          // the other buffer: nobody reads it before the barrier below
         // lane holds S^T[item row][user = col] for rows 8*(j/4) + 4*kh + (j%4), j = 0..15
         const int64_t i0 = c * TN_TILE;
+        // A user's two lanes each keep the best N of their own half of the items; the user's N-th best over
+        // both halves is at least the larger of the two lanes' N-th bests, so that is the bar a candidate has
+        // to pass (strictly: equal scores are settled by the list itself).
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sc[N - 1]), __float_as_uint(sc[N - 1]), false, false);
+        const float other = __uint_as_float(kh ? sw[0] : sw[1]);
+        const float bar = fmaxf(sc[N - 1], other);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = 8 * (j / 4) + 4 * kh + (j % 4);
             const int64_t item = i0 + row;
             const float s = acc[j] + bc[buf * TN_TILE + row];
-            const bool cand = item < n_items && (s > sc[N - 1] || (s == sc[N - 1] && (int32_t)item < id[N - 1]));
+            const bool cand = item < n_items && s >= bar &&
+                              (s > sc[N - 1] || (s == sc[N - 1] && (int32_t)item < id[N - 1]));
+#ifdef TN_NOSELECT   // timing experiment: multiply only (one value is kept so the MFMAs are not dead code)
+            if (s == 12345.678f) sc[0] = s;
+#else
             if (__ballot(cand)) insert_top<N>(sc, id, cand ? s : -INFINITY, cand ? (int32_t)item : 0x7fffffff);
+#endif
         }
         __syncthreads();
     }
@@ -127,7 +174,7 @@ int launch_topn(const float *P, const float *Q, const float *b_u, const float *b
                 int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
                 hipStream_t st)
 {
-    const int kpad = (k + 1) & ~1;
+    const int kpad = (k + 7) & ~7;
     const size_t ld = (size_t)kpad + 1;
     const size_t bytes = ((size_t)(TN_WAVES + 2) * TN_TILE * ld + 2 * TN_TILE) * sizeof(float);
     MF_ARG(bytes <= (size_t)160 * 1024, "topn: k=%d needs %zu bytes of LDS", k, bytes);
