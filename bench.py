@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--renumber", default="balanced", choices=["balanced", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20240611)
+    ap.add_argument("--hot-batch", type=int, default=8,
+                    help="apply the updates of each stripe's most rated item in groups of this size "
+                         "(mfsgd_grid_set_hot_batch; 1 = the reference's sequential order inside a block)")
     ap.add_argument("--swap-roles", action="store_true",
                     help="experiment: feed the data with users and items swapped (which side is LDS-stationary)")
     args = ap.parse_args()
@@ -151,7 +154,7 @@ def main():
                                (ALPHA, BETA1, BETA2))
     m = ra.ExplicitMF(n_threads=15, n_factors=k, alpha=ALPHA, beta1=BETA1, beta2=BETA2, implicit=args.implicit,
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
-                      n_workgroups=args.wgs, waves_per_wg=args.waves, verbose=False)
+                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_batch=args.hot_batch, verbose=False)
     m.load_samples_from_device(train, test, U, I)
     import numpy as np
     np.random.seed(args.seed % (2 ** 31))
@@ -197,7 +200,9 @@ def main():
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shape {U}x{I}, {n_train} train ratings, k={k}, implicit={args.implicit}, "
-                               f"grid {grid.info.Gr}x{grid.info.Gc}, {args.renumber} renumbering, free-block schedule",
+                               f"grid {grid.info.Gr}x{grid.info.Gc}, {args.renumber} renumbering, free-block schedule"
+                               + (f", hot-item groups of {args.hot_batch}" if args.hot_batch > 1 else ""),
+                   "hot_batch": args.hot_batch,
                    "n_train": n_train, "k": k, "grid": [grid.info.Gr, grid.info.Gc], "prep_seconds": prep_s,
                    "max_col_nnz": int(grid.info.max_col_nnz), "max_block": int(grid.info.max_block)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

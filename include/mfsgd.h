@@ -127,7 +127,7 @@ typedef struct {
     int32_t user_unique;  /* 1 if no user has two runs in one block */
     int64_t max_block, max_col_nnz, max_row_nnz;
     int32_t n_served;     /* item stripes whose most rated item gets a server wave in the free-block kernel */
-    int32_t reserved;
+    int32_t n_hot_stripes; /* item stripes whose most rated item carries >= 1/16 of the stripe's ratings (user_unique grids) */
 } mfsgd_grid_info;
 
 /* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);
@@ -140,6 +140,21 @@ void mfsgd_grid_destroy(mfsgd_grid *g);
  * run_user[n_runs], item[n], val[n], tick[n].  For checking the bucketing bit for bit. */
 int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_start, int32_t *run_user,
                       int32_t *item, float *val, int32_t *tick, void *stream);
+/* Opt-in relaxation of the order INSIDE a block, for the free-block and the fixed schedule alike (group = 1, the
+ * default, is the reference's sequential order, numba_methods.py:11-23).  With group = 2,4,..,64 the ratings of
+ * each stripe's most rated item (mfsgd_grid_info.n_hot_stripes of them qualify) are taken in groups of `group`
+ * in stored order: every member of group g reads the item's row and bias in version V_g, where V_0 = V_1 = the
+ * values at the start of the block and V_{g+2} = V_{g+1} + the summed changes of group g - mini-batches of
+ * `group` on that one item whose result becomes visible one group late, plain SGD everywhere else.  The reference has no such mode: its own parallel runs (RayBlockScheduler.py:148-181) keep one block
+ * sequential and accept any order ACROSS blocks; this mode is judged as north_star judges the throughput path,
+ * by RMSE (tests: within 0.002 of the sequential order), and stays checkable update by update against the
+ * oracle's restatement of it (orc_sgd_hotbatch).  Why: one item's updates form a serial chain; on Netflix-shaped
+ * data the most rated items carry 10^5 ratings each and that chain, not the memory system, bounds their stripes.
+ * Needs a grid with user_unique = 1 unless group == 1.  Takes effect from the next epoch call. */
+int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group);
+/* h_col_hot[Gc] (HOST): for every item stripe the global id of the item mfsgd_grid_set_hot_batch applies to,
+ * or -1.  Synchronises. */
+int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream);
 /* Synchronises and reports whether an epoch kernel ran out of patience on a wait (every spin in the
  * kernels is bounded); clears the flag. */
 int mfsgd_grid_status(mfsgd_grid *g, void *stream);

@@ -22,7 +22,7 @@ class GridInfo(C.Structure):
                 ("Gr", c_i32), ("Gc", c_i32), ("ubp", c_i32), ("ibp", c_i32),
                 ("order", c_i32), ("user_unique", c_i32),
                 ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64),
-                ("n_served", c_i32), ("reserved", c_i32)]
+                ("n_served", c_i32), ("n_hot_stripes", c_i32)]
 
 
 def _sig_sgd(ct):
@@ -63,6 +63,8 @@ SIGNATURES = {
     "mfsgd_grid_get_info": (C.c_int, [c_vp, C.POINTER(GridInfo)]),
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mfsgd_grid_set_hot_batch": (C.c_int, [c_vp, c_i32]),
+    "mfsgd_grid_col_hot": (C.c_int, [c_vp, c_vp, c_vp]),
     "mfsgd_grid_status": (C.c_int, [c_vp, c_vp]),
     "mfsgd_grid_col_times": (C.c_int, [c_vp, c_vp, c_vp]),
     "mfsgd_hip_epoch_f32": (C.c_int, _sig_epoch(c_f32)),

@@ -54,6 +54,8 @@ struct mfsgd_grid {
     int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings of that item in the block
     int32_t *col_hot_deg = nullptr;  // [Gc] ratings of that item in the whole stripe (0 when col_hot < 0)
     int32_t max_block_runs = 0;
+    int32_t hot_batch = 1;         // > 1: updates of a stripe's most rated item are applied in groups of this size
+    bool serve_env = false;        // MFSGD_SERVE_HOT at creation: server wave instead (experimental)
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -72,6 +74,8 @@ struct GridView {
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
     const int32_t *col_hot, *blk_hot_cnt, *col_hot_deg;
+    int32_t hot_mode;   // what happens to a stripe's most rated item: 0 nothing special, 1 server wave, 2 grouped updates
+    int32_t hot_shift;  // mode 2: log2 of the group size
 };
 
 struct SchedView {
@@ -325,11 +329,17 @@ template <typename T> struct HotRing {
     T *p;          // [HOT_R][k]
     int *ui;       // [HOT_R][2]  {user, 1 = the worker wants the row back | 0 = last rating of its run: the server stores it}
     int32_t item;  // global id of the served item, -1: nobody is served in this stripe
+    // Grouped updates (mfsgd_grid_set_hot_batch) reuse the ring's memory, see walk_run.
+    // shift = log2(group size), 0: the ring serves; n_blk = ratings of the item in the current block.
+    int32_t shift, n_blk;
 };
 
 template <typename T>
-LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic)
+LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic, int32_t group = 1)
 {
+    // grouped updates keep one row per member of the two open groups, plus the odd versions' row (walk_run)
+    const size_t ring_rows = std::max<size_t>(HOT_R, group > 1 ? 2 * (size_t)group + 1 : 0);
+    const size_t ring_words = std::max<size_t>(2 * HOT_R, group > 1 ? 2 * (size_t)group + 4 : 0);
     auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsPlan<T> p{};
     size_t o = 0;
@@ -340,8 +350,8 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
     p.ring_st = o; o = up(o + (stage ? (size_t)HOT_R * 4 : 0));
-    p.ring_s = o; o = up(o + (stage ? (size_t)HOT_R * 2 * sizeof(T) : 0));
-    p.ring_p = o; o = up(o + (stage ? (size_t)HOT_R * k * sizeof(T) : 0));
+    p.ring_s = o; o = up(o + (stage ? ring_words * sizeof(T) : 0));
+    p.ring_p = o; o = up(o + (stage ? ring_rows * k * sizeof(T) : 0));
     p.ring_ui = o; o = up(o + (stage ? (size_t)HOT_R * 8 : 0));
     p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.rt_t = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
@@ -473,7 +483,102 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         const int32_t il = ig - c_base;
         int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
-        if (HOT && ig == hot.item) {
+        if (HOT && !CUM && ig == hot.item && hot.shift > 0) {
+            // Grouped updates of the stripe's most rated item (opt-in).  The item's ratings tk
+            // with the same g = tk >> shift form a group.  Every member of group g reads the item's row and
+            // bias in version V_g (V_0 = V_1 = the block's starting values), adds its change to the sums of its
+            // group's parity and moves on; whoever finishes a group last forms V_{g+2} = V_{g+1} + sums and
+            // publishes it.  A group's changes thus reach the group after the next: the members of a group sit
+            // in different runs, i.e. on different waves, and with two groups in flight no wave waits for the
+            // item unless it is a whole group ahead of the slowest one - the item's chain of single hand-offs,
+            // which bounds the stripes of the most rated items, is gone.
+            // Sums are not formed with LDS float atomics (measured: they cost more than the chain they replace):
+            // every member stores its change in its own slot and the closer adds the slots up in member order,
+            // so the result does not depend on who finished when.
+            // LDS (HotRing memory): st[0] = newest published version, st[1 + par] = members of the open group
+            // of that parity that are done; p[(par * B + m) * k ..] / s[3 + par * B + m] = the change member m of
+            // that group computed; versions of even groups live in the stripe's own row, those of odd groups in
+            // p[2B * k ..] / s[2].
+            const int32_t grp = tk >> hot.shift, par = grp & 1, gfirst = grp << hot.shift;
+            int32_t gend = gfirst + (1 << hot.shift);
+            if (gend > hot.n_blk) gend = hot.n_blk;
+            const int32_t gsize = gend - gfirst;
+            const bool last = gend == hot.n_blk;
+            const size_t own = (size_t)il * k, alt = (size_t)((hot.p + ((size_t)2 << hot.shift) * k) - qs);  // one base: DS addressing
+            const size_t mine = par ? alt : own, other = par ? own : alt;
+            T *bmine = par ? &hot.s[2] : &bis[il], *bother = par ? &bis[il] : &hot.s[2];
+            T bi;
+            for (int spins = 0;; ++spins) {
+                const int32_t seen = __hip_atomic_load(hot.st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // LDS answers a wave in issue order
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const int f = lane + 64 * c;
+                    q[c] = (FAST || f < k) ? qs[mine + f] : (T)0;
+                }
+                bi = *bmine;
+                if (__builtin_amdgcn_readfirstlane(seen) >= grp) break;
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                __builtin_amdgcn_s_sleep(TICKET_NAP);
+            }
+            T part = 0;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) part += q[c] * (FAST ? p[c] : p[c] + zz[c]);
+            const T e = r - b - bu - bi - wave_sum(part);
+            const int32_t gslot = (par << hot.shift);          // first slot of this group
+            T *slotq = hot.p + (size_t)(gslot + (tk - gfirst)) * k;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int f = lane + 64 * c;
+                const T pnew = p[c] + alpha * (e * q[c] - beta2 * p[c]);
+                const T pu = variant == 0 ? pnew : p[c];
+                if (FAST || f < k) slotq[f] = alpha * (e * (FAST ? pu : pu + zz[c]) - beta2 * q[c]);
+                p[c] = pnew;
+            }
+            *sink_ptr(&hot.s[3 + gslot + (tk - gfirst)], ctl, lane) = alpha * (e - beta1 * bi);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const int32_t cnt = __builtin_amdgcn_readlane(atomicAdd(sink_ptr(hot.st + 1 + par, ctl, lane), 1), 0) + 1;
+            if (cnt == gsize) {
+                // every member stored its change before it counted itself: the slots are complete.  V_{g+1} is
+                // published by the previous group's closer - nearly always long ago.
+                for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                        hot.st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < grp + 1; ++spins) {
+                    if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                T v[KC], nb = *bother;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const int f = lane + 64 * c;
+                    v[c] = (FAST || f < k) ? qs[other + f] : (T)0;
+                }
+                T dsum[KC] = {}, dbs = 0;
+                for (int32_t m = 0; m < gsize; ++m) {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        const int f = lane + 64 * c;
+                        if (FAST || f < k) dsum[c] += hot.p[(size_t)(gslot + m) * k + f];
+                    }
+                    dbs += hot.s[3 + gslot + m];
+                }
+                // V_{g+2} replaces V_g (all its readers are done); the block's last group leaves it in the stripe
+                const size_t dst = last ? own : mine;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const int f = lane + 64 * c;
+                    if (FAST || f < k) qs[dst + f] = v[c] + dsum[c];
+                }
+                *sink_ptr(last ? &bis[il] : bmine, ctl, lane) = nb + dbs;
+                *sink_ptr(hot.st + 1 + par, ctl, lane) = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __hip_atomic_store(sink_ptr(hot.st, ctl, lane), grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            bu += alpha * (e - beta1 * bu);
+            PF_INC(PF_RATINGS, 1);
+            continue;
+        }
+        if (HOT && FAST && ig == hot.item && hot.shift == 0) {
             // the stripe's served item: hand the user row to the server wave and take the answer (HotRing)
             if (CUM) tk += __builtin_amdgcn_readfirstlane(tbase[il]);
             const int32_t hs = tk & (HOT_R - 1), gen3 = 3 * (tk / HOT_R);
@@ -724,7 +829,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
                                               int *tick_done, T *qs, T *bis, int32_t *err, HotRing<T> hot, int *rt_u,
                                               int *rt_t, int32_t run_lo, int32_t run_hi, int32_t n_hot_blk PF_PARAM)
 {
-    constexpr bool HOT = STAGE && FAST;
+    constexpr bool HOT = STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
     const int32_t c_base = c * g.ibp;
@@ -734,11 +839,22 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     const bool uniq = FAST || g.user_unique;     // host side: FAST kernels are only launched on user-unique grids
     int32_t n_hot = 0;
     if (HOT) {
-        // a server needs workers beside it; a block too long for one run table is walked in chunks with barriers
-        // between them, which a serving wave could not attend
-        if (nw < 4 || run_hi - run_lo > RT_CAP) hot.item = -1;
-        if (hot.item >= 0) n_hot = n_hot_blk;
-        if (tid < HOT_R) hot.st[tid] = 0;
+        if (hot.shift > 0) {
+            // grouped updates: counters and sums start at zero in every block
+            hot.n_blk = n_hot_blk;
+            if (hot.item >= 0 && n_hot_blk > 0) {
+                const int32_t hl = hot.item - c_base;
+                for (int i = tid; i < k; i += blockDim.x)
+                    hot.p[((size_t)2 << hot.shift) * k + i] = qs[(size_t)hl * k + i];   // V_1 = V_0
+                if (tid == 0) hot.s[2] = bis[hl];
+            }
+        } else {
+            // a server needs workers beside it; a block too long for one run table is walked in chunks with barriers
+            // between them, which a serving wave could not attend
+            if (!FAST || nw < 4 || run_hi - run_lo > RT_CAP) hot.item = -1;
+            if (hot.item >= 0) n_hot = n_hot_blk;
+        }
+        if (tid < HOT_R) hot.st[tid] = tid == 0 && hot.shift > 0 ? 1 : 0;   // grouped: versions 0 and 1 exist
     }
     if (uniq) {
     for (int32_t lo = run_lo; lo < run_hi; lo += RT_CAP) {   // one trip unless the block has more than RT_CAP runs
@@ -751,7 +867,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     }
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
-    if (HOT && n_hot > 0 && __builtin_amdgcn_readfirstlane(wave) == nw - 1) {
+    if (HOT && FAST && n_hot > 0 && __builtin_amdgcn_readfirstlane(wave) == nw - 1) {
         // ---- server of the stripe's most rated item (HotRing): row and bias in registers for the whole block
         serve_hot<T, KC>(hot, n_hot, hot.item - c_base, qs, bis, k, lane, ctl, b, alpha, beta1, beta2, variant, P, b_u, err,
                          n_hot >= 150 PF_PASS);
@@ -879,11 +995,14 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
 #endif
-    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), (int *)(smem + lp.ring_ui), -1};
+    const bool grouped = STAGE && g.hot_mode == 2;
+    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), (int *)(smem + lp.ring_ui),
+                         grouped ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1, grouped ? g.hot_shift : 0, 0};
     process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
                                        bis, s.err, hot, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
                                        __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
-                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), 0 PF_PASS);
+                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]),
+                                       grouped ? __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[r * g.Gc + c]) : 0 PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -938,7 +1057,9 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, 
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
         const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             (int *)(smem + lp.ring_ui), __builtin_amdgcn_readfirstlane(g.col_hot[c])};
+                             (int *)(smem + lp.ring_ui),
+                             STAGE && g.hot_mode ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1,
+                             g.hot_mode == 2 ? g.hot_shift : 0, 0};
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -1144,7 +1265,8 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_stream(GridView g, T *P, T *Q
         stripe_load<T, true>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             (int *)(smem + lp.ring_ui), __builtin_amdgcn_readfirstlane(g.col_hot[c])};
+                             (int *)(smem + lp.ring_ui),
+                             g.hot_mode == 1 ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1, 0, 0};
         const int32_t hot_total = __builtin_amdgcn_readfirstlane(g.col_hot_deg[c]);
         if (wave == 0) {
             // ------------------------------------------------------------------ scheduler
@@ -1379,7 +1501,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
                   int32_t *order_log, hipStream_t st)
 {
     const bool dynamic = schedule == 1;
-    const LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic);
+    const LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_batch);
     if (waves <= 0) waves = 16;
     if (waves > 16) waves = 16;
     const int threads = waves * 64;
@@ -1411,7 +1533,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         n_wg = prop.multiProcessorCount * per_cu;
     }
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
-    if (STAGE && fast && gv.user_unique && waves >= 4 && G->max_block_runs <= RT_CAP && getenv("MFSGD_STREAM")) {   // experimental, see DESIGN.md
+    if (STAGE && fast && gv.user_unique && waves >= 4 && G->max_block_runs <= RT_CAP && gv.hot_mode != 2 && getenv("MFSGD_STREAM")) {   // experimental, see DESIGN.md
         StreamPlan sp = stream_plan<T>(gv.ibp, gv.Gr, k);
         const char *dep = getenv("MFSGD_STREAM_DEPTH");
         sp.depth = dep ? atoi(dep) : 2;
@@ -1460,10 +1582,17 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->col_hot_deg};
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->col_hot_deg,
+                G->hot_batch > 1 ? 2 : (G->serve_env ? 1 : 0), 0};
+    while ((1 << gv.hot_shift) < G->hot_batch) ++gv.hot_shift;
     const bool dynamic = schedule == 1;
     const size_t cap = (size_t)160 * 1024;
-    const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
+    const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic, G->hot_batch).total <= cap;
+    if (!stage && G->hot_batch > 1) {
+        mfsgd_set_error("epoch: groups of %d need the item stripe (%d items, k=%d) and %d more rows in LDS; use a finer "
+                        "grid or smaller groups", G->hot_batch, in.ibp, k, 2 * G->hot_batch + 1);
+        return MFSGD_ERR_GRID;
+    }
     if (!stage && lds_plan<T>(in.ibp, in.Gr, k, false, dynamic).total > cap) {
         mfsgd_set_error("epoch: item stripes of %d items (or %d row stripes) do not fit LDS; use a finer grid",
                         in.ibp, in.Gr);
@@ -1512,6 +1641,25 @@ int mfsgd_grid_status(mfsgd_grid *g, void *stream)
                         (h & 1) ? "item ticket " : "", (h & 2) ? "row lock" : "");
         return MFSGD_ERR_GRID;
     }
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group)
+{
+    MF_ARG(g, "grid_set_hot_batch: null grid");
+    MF_ARG(group >= 1 && group <= 64 && (group & (group - 1)) == 0, "grid_set_hot_batch: group=%d is not a power of two in [1,64]",
+           group);
+    MF_ARG(group == 1 || g->info.user_unique, "grid_set_hot_batch: grouped updates need a grid whose users have one run per block");
+    g->hot_batch = group;
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream)
+{
+    MF_ARG(g && h_col_hot, "grid_col_hot: null pointer");
+    hipStream_t st = as_stream(stream);
+    MF_HIP(hipMemcpyAsync(h_col_hot, g->col_hot, sizeof(int32_t) * (size_t)g->info.Gc, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
     return MFSGD_OK;
 }
 
@@ -1726,7 +1874,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     }
     // 5b. the item of every stripe whose chain gets a server wave, and how often it occurs in each block
     // Experimental (MFSGD_SERVE_HOT=1): measured slower than the LDS tickets it replaces.
-    if (G->info.user_unique && getenv("MFSGD_SERVE_HOT")) {
+    G->serve_env = getenv("MFSGD_SERVE_HOT") != nullptr;
+    if (G->info.user_unique) {
         DevBuf deg;
         MF_HIP(deg.alloc((size_t)n_items * 4));
         MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
@@ -1741,7 +1890,10 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         std::vector<int32_t> h_hot((size_t)Gc);
         MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
-        for (int32_t v : h_hot) G->info.n_served += v >= 0;
+        for (int32_t v : h_hot) {
+            G->info.n_hot_stripes += v >= 0;
+            G->info.n_served += G->serve_env && v >= 0;
+        }
     }
     MF_HIP(hipStreamSynchronize(st));
     // 6. stripe weights (host, Gr*Gc words): heaviest item stripe first

@@ -250,14 +250,14 @@ def _synthetic(rng, U, I, n, lead=False):
     (64, 3000, 600, 120000, (4, 12), 16),      # 750 users per stripe: blocks longer than the LDS run table (chunks)
 ])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
-def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode):
+def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode, hot_batch=1, schedule=1):
     """The on-GPU scheduler may issue blocks in any conflict-free order; its log, replayed block by block
     through the CPU oracle, must reproduce the GPU factors (fp32 tolerance), every block exactly once/epoch."""
     import torch
     from recommender_amd import _abi
     from recommender_amd.SGDRecommender import Grid
     rng = np.random.default_rng(k + n)
-    s = _synthetic(rng, U, I, n, lead=k in (64, 128))
+    s = _synthetic(rng, U, I, n, lead=k in (64, 128) or hot_batch > 1)
     Gr, Gc = grid
     ubp, ibp = -(-U // Gr), -(-I // Gc)
     Gr, Gc = -(-U // ubp), -(-I // ibp)
@@ -268,6 +268,12 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
         assert gr.info.n_served > 0 or k not in (64, 128)   # the server-wave path runs in the k=64,128 "none" cases
     else:
         assert gr.info.n_served == 0
+    col_hot = np.full(Gc, -1)
+    if hot_batch > 1:
+        gr.set_hot_batch(hot_batch)
+        col_hot = gr.col_hot()
+        assert gr.info.n_hot_stripes == (col_hot >= 0).sum() > 0
+        assert all(h < 0 or h // ibp == c for c, h in enumerate(col_hot))
     P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
     Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
     y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
@@ -280,9 +286,9 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
     iters = 2
     log = torch.full((iters * Gr * Gc, 2), -1, dtype=torch.int32, device="cuda")
     _abi.check(_abi.lib().mfsgd_hip_epoch_f32(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
-                                              b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, 1, 1234, 0,
-                                              waves, _abi.ptr(log), None))
-    torch.cuda.synchronize()
+                                              b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, schedule, 1234,
+                                              0, waves, _abi.ptr(log), None))
+    gr.status()
     log = log.cpu().numpy().reshape(iters, Gr * Gc, 2)
     # oracle replay: the same blocks (user-sorted inside a block, as order=1 stores them) in logged order
     key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
@@ -295,9 +301,40 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
         assert len(issued) == len(set(issued)) and set(issued) == nonempty
         for r, c in issued:
             blk = ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]]
-            orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z)
+            orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z,
+                    hot_item=int(col_hot[c]), hot_batch=hot_batch)
     for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
         assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= 1e-4, name
+
+
+@pytest.mark.parametrize("group", [2, 8, 64])
+def test_grouped_hot_item_updates_replay_on_oracle(ra, orc, group):
+    """mfsgd_grid_set_hot_batch: the opt-in grouped updates of each stripe's most rated item are still one
+    well-defined computation - the logged block order replayed through the oracle's restatement of the grouping
+    (orc_sgd_hotbatch) reproduces the GPU factors.  FAST (k = 64, 128) and general kernels, both schedules,
+    blocks longer than the run table, implicit term on and off."""
+    f = test_free_block_schedule_replays_on_oracle
+    f(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_batch=group)
+    f(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_batch=group)
+    f(ra, orc, 64, 3000, 600, 120000, (4, 12), 16, "frozen", hot_batch=group)
+    f(ra, orc, 200, 700, 400, 40000, (16, 8), 8, "frozen", hot_batch=group)
+    f(ra, orc, 32, 500, 300, 30000, (8, 6), 4, "none", hot_batch=group, schedule=0)
+
+
+def test_grouped_hot_item_updates_arguments(ra):
+    import torch
+    from recommender_amd import _abi
+    from recommender_amd.SGDRecommender import Grid
+    s = _synthetic(np.random.default_rng(0), 200, 100, 5000)
+    gr = Grid(torch.from_numpy(s).cuda(), 200, 100, 50, 25, order=1)
+    for bad in (0, 3, 128, -4):
+        with pytest.raises(Exception, match="power of two"):
+            gr.set_hot_batch(bad)
+    gr.set_hot_batch(4); gr.set_hot_batch(1)
+    g0 = Grid(torch.from_numpy(s).cuda(), 200, 100, 50, 25, order=0)      # reference order: users recur in a block
+    if not g0.info.user_unique:
+        with pytest.raises(Exception, match="one run per block"):
+            g0.set_hot_batch(4)
 
 
 def test_server_wave_replays_on_oracle(ra, orc, monkeypatch):
@@ -337,9 +374,11 @@ def test_throughput_mode_rmse_close_to_deterministic(ra):
     pu, qi = rng.normal(scale=0.6, size=(U, 8)), rng.normal(scale=0.6, size=(I, 8))
     s[:, 2] = np.clip(np.rint(3.5 + (pu[s[:, 0]] * qi[s[:, 1]]).sum(1) + rng.normal(scale=0.5, size=len(s))), 1, 5)
     out = {}
-    for det in (True, False):
-        m = ra.ExplicitMF(n_threads=7, n_factors=32, alpha=0.02, implicit="none", deterministic=det,
-                          grid=None if det else (64, 32), verbose=False)
+    for det in (True, False, "sequential"):
+        m = ra.ExplicitMF(n_threads=7, n_factors=32, alpha=0.02, implicit="none", deterministic=det is True,
+                          grid=None if det is True else (64, 32), hot_batch=1 if det == "sequential" else None,
+                          verbose=False)
+        assert m.hot_batch == {True: 1, False: 8, "sequential": 1}[det]
         np.random.seed(9)
         m.load_samples_from_array(s, "all")
         m.generate_indpendent_samples_new()
@@ -351,6 +390,8 @@ def test_throughput_mode_rmse_close_to_deterministic(ra):
     # order noise, ~5e-3 at this size; north_star's 0.002 bar is checked where it is defined, at full size
     # (bench.py reports held-out RMSE; profiles/rmse_parity_r1.txt holds the fixed-order vs free-block runs)
     assert abs(out[False][1] - out[True][1]) < 0.01 and abs(out[False][0] - out[True][0]) < 0.01
+    # grouped updates of the stripes' most rated items (the throughput default) against sequential free-block runs
+    assert abs(out[False][1] - out["sequential"][1]) < 0.01 and abs(out[False][0] - out["sequential"][0]) < 0.01
 
 
 def test_train_api_end_to_end(ra):
