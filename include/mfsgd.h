@@ -152,6 +152,11 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
  * data the most rated items carry 10^5 ratings each and that chain, not the memory system, bounds their stripes.
  * Needs a grid with user_unique = 1 unless group == 1.  Takes effect from the next epoch call. */
 int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group);
+/* Host-side helper for choosing a grid: bytes of LDS a free-block workgroup needs for item stripes of `ibp`
+ * items, `Gr` user stripes, k factors of `elem_size` bytes (4 or 8) and groups of `group` (1 = none); -1 on bad
+ * arguments.  A CU has 160 KB: <= 80 KB lets two workgroups share one.  Touches no device.  No counterpart in the
+ * reference (its grid is (n_threads+1)^2, SGDRecommender.py:189-192). */
+int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t group);
 /* h_col_hot[Gc] (HOST): for every item stripe the global id of the item mfsgd_grid_set_hot_batch applies to,
  * or -1.  Synchronises. */
 int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream);

@@ -71,6 +71,27 @@ def balanced_permutation(deg, width):
     return new_id
 
 
+def lds_bytes(ibp, Gr, k, esz, group=1):
+    """LDS a free-block workgroup needs for item stripes of `ibp` items (lds_plan in csrc/epoch.hip, kept in
+    step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes)."""
+    up = lambda x: (x + 15) & ~15
+    rows = max(16, 2 * group + 1 if group > 1 else 0)
+    words = max(32, 2 * group + 4 if group > 1 else 0)
+    o = up((16 + 128) * 4)
+    o = up(o + ibp * 4)
+    o = up(o + Gr)
+    o = up(o + Gr * 12)
+    o = up(o + ibp * k * esz)
+    o = up(o + ibp * esz)
+    o = up(o + 16 * 4)
+    o = up(o + words * esz)
+    o = up(o + rows * k * esz)
+    o = up(o + 16 * 8)
+    o = up(o + 514 * 4)
+    o = up(o + 514 * 4)
+    return o
+
+
 class Grid:
     """Owner of a device block grid (mfsgd_grid_*)."""
 
@@ -246,26 +267,35 @@ class ExplicitMF(Recommender):
 
     # ------------------------------------------------------------------ the GPU FPSGD path
     def _choose_grid(self):
-        """Throughput grid: item stripes narrow enough for the Q stripe (+b_i, tickets) to sit in LDS next
-        to the scheduler words, up to 512 item stripes (two 16-wave workgroups per CU) and 640 user
-        stripes (a quarter more rows than workgroups: measured best on MI355X, profiles/), shrunk together
-        for small inputs so that a block still holds ~128 ratings (the per-block cost - lock, fences,
-        barriers - is several microseconds)."""
+        """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table, the rows of
+        the open groups) in LDS, and a CU has 160 KB of it: stripes of <= 80 KB run two 16-wave workgroups per
+        CU (512 at a time), larger ones one (256).  The epoch is a whole number of such rounds, so the stripe
+        count is made 512 or 256 whenever the data allow it - 374 stripes of 86 KB cost ml25m two rounds, the
+        second one a third full (18.4 ms; 256 stripes: 11.1 ms, profiles/).  User stripes: a quarter more than
+        workgroups in flight (row locks are taken at random; measured best on MI355X).  Small inputs shrink both
+        so that a block still holds ~128 ratings (per-block cost - lock, fences, barriers - is microseconds)."""
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
             k = self.n_factors
             esz = 8 if self.dtype == "float64" else 4
-            ring = (2 * self.hot_batch + 1) * k * esz if self.hot_batch > 1 else 0    # LDS rows of the open groups
-            ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
-            Gc_min = -(-self.n_items // ibp_max)
-            Gc, Gr = min(self.n_items, 512), min(self.n_users, 640)
             n = int(self._d_samples.shape[0])
-            want = max(1.0, n / 128.0)
-            if Gr * Gc > want:
-                f = (want / (Gr * Gc)) ** 0.5
-                Gr, Gc = max(1, int(Gr * f)), max(1, int(Gc * f))
-            Gc = min(self.n_items, max(Gc, Gc_min))
+            U, I = self.n_users, self.n_items
+            fits = lambda Gr_, Gc_, cap: lds_bytes(-(-I // Gc_), Gr_, k, esz, self.hot_batch) <= cap
+            if U >= 640 and I >= 512 and n >= 150 * 640 * 512 and fits(640, 512, 80 * 1024):
+                Gr, Gc = 640, 512
+            elif U >= 320 and I >= 256 and n >= 128 * 320 * 256 and fits(320, 256, 160 * 1024):
+                Gr, Gc = 320, 256
+            else:
+                ring = (2 * self.hot_batch + 1) * k * esz if self.hot_batch > 1 else 0    # LDS rows of the open groups
+                ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
+                Gc_min = -(-I // ibp_max)
+                Gc, Gr = min(I, 512), min(U, 640)
+                want = max(1.0, n / 128.0)
+                if Gr * Gc > want:
+                    f = (want / (Gr * Gc)) ** 0.5
+                    Gr, Gc = max(1, int(Gr * f)), max(1, int(Gc * f))
+                Gc = min(I, max(Gc, Gc_min))
         ubp = -(-self.n_users // Gr)
         ibp = -(-self.n_items // Gc)
         return ubp, ibp

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mfsgd_grid_get_info": (C.c_int, [c_vp, C.POINTER(GridInfo)]),
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mfsgd_lds_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "mfsgd_grid_set_hot_batch": (C.c_int, [c_vp, c_i32]),
     "mfsgd_grid_col_hot": (C.c_int, [c_vp, c_vp, c_vp]),
     "mfsgd_grid_status": (C.c_int, [c_vp, c_vp]),

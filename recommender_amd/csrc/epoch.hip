@@ -1644,6 +1644,13 @@ int mfsgd_grid_status(mfsgd_grid *g, void *stream)
     return MFSGD_OK;
 }
 
+int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t group)
+{
+    if (ibp < 1 || Gr < 1 || k < 1 || group < 1 || (elem_size != 4 && elem_size != 8)) return -1;
+    return elem_size == 8 ? (int64_t)lds_plan<double>(ibp, Gr, k, true, true, group).total
+                          : (int64_t)lds_plan<float>(ibp, Gr, k, true, true, group).total;
+}
+
 int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group)
 {
     MF_ARG(g, "grid_set_hot_batch: null grid");
