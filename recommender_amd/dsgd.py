@@ -94,14 +94,16 @@ def gather_items(plan, rank, Q, b_i, dist):
 
 
 def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, hot_batch=1):
-    """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~64+ ratings, with
-    up to 256 column stripes per shard (one workgroup each) and twice as many row stripes as columns."""
+    """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~170+ ratings, with
+    up to 256 column stripes per shard (one workgroup each) and a quarter more row stripes than columns.
+    Measured with profiles/dsgd_rank_sim.py (netflix shape, one rank's kernels alone): blocks of ~70 ratings
+    cost world=4 7.7 ms per sub-epoch, blocks of ~170 5.0 ms; world=8 is flat between 12K and 22K blocks."""
     ring = (2 * hot_batch + 1) * k * esz if hot_batch > 1 else 0
     ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
     cols = min(256, max(1, n_items // world))
     rows = min(cols + cols // 4, max(1, n_users // world))
     per = n_train / float(world * world)
-    want = max(1.0, per / 64.0)
+    want = max(1.0, per / 170.0)
     if rows * cols > want:
         f = (want / (rows * cols)) ** 0.5
         rows, cols = max(1, int(rows * f)), max(1, int(cols * f))
