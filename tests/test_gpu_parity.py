@@ -250,7 +250,8 @@ def _synthetic(rng, U, I, n, lead=False):
     (64, 3000, 600, 120000, (4, 12), 16),      # 750 users per stripe: blocks longer than the LDS run table (chunks)
 ])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
-def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode, hot_batch=1, schedule=1):
+def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode, hot_batch=1, schedule=1,
+                                               dt=np.float32, tol=1e-4):
     """The on-GPU scheduler may issue blocks in any conflict-free order; its log, replayed block by block
     through the CPU oracle, must reproduce the GPU factors (fp32 tolerance), every block exactly once/epoch."""
     import torch
@@ -274,10 +275,10 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
         col_hot = gr.col_hot()
         assert gr.info.n_hot_stripes == (col_hot >= 0).sum() > 0
         assert all(h < 0 or h // ibp == c for c, h in enumerate(col_hot))
-    P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
-    Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
-    y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
-    bu, bi = np.zeros(U, np.float32), np.zeros(I, np.float32)
+    P = rng.normal(scale=1 / k, size=(U, k)).astype(dt)
+    Q = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
+    y = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
+    bu, bi = np.zeros(U, dt), np.zeros(I, dt)
     b = float(s[:, 2].mean())
     rp, ci = orc.csr_from_coo(s, U)
     z = orc.implicit_z(y, rp, ci, U) if mode == "frozen" else None
@@ -285,9 +286,10 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
     dz = torch.from_numpy(z).cuda() if z is not None else None
     iters = 2
     log = torch.full((iters * Gr * Gc, 2), -1, dtype=torch.int32, device="cuda")
-    _abi.check(_abi.lib().mfsgd_hip_epoch_f32(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
-                                              b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, schedule, 1234,
-                                              0, waves, _abi.ptr(log), None))
+    fn = _abi.lib().mfsgd_hip_epoch_f32 if dt == np.float32 else _abi.lib().mfsgd_hip_epoch_f64
+    _abi.check(fn(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
+                  b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, schedule, 1234,
+                  0, waves, _abi.ptr(log), None))
     gr.status()
     log = log.cpu().numpy().reshape(iters, Gr * Gc, 2)
     # oracle replay: the same blocks (user-sorted inside a block, as order=1 stores them) in logged order
@@ -304,7 +306,17 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
             orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z,
                     hot_item=int(col_hot[c]), hot_batch=hot_batch)
     for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
-        assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= 1e-4, name
+        assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= tol, name
+
+
+def test_free_block_and_grouped_updates_in_float64(ra, orc):
+    """The fp64 epoch kernels against the fp64 oracle: the logged order replays to 1e-9 (summation trees differ),
+    with and without grouped updates - the group sums are formed in member order, so they are not timing-dependent."""
+    f = test_free_block_schedule_replays_on_oracle
+    for hb in (1, 8):
+        f(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_batch=hb, dt=np.float64, tol=1e-9)
+        f(ra, orc, 40, 700, 400, 40000, (16, 8), 8, "frozen", hot_batch=hb, dt=np.float64, tol=1e-9)
+        f(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_batch=hb, schedule=0, dt=np.float64, tol=1e-9)
 
 
 @pytest.mark.parametrize("group", [2, 8, 64])
