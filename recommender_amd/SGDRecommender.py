@@ -269,7 +269,8 @@ class ExplicitMF(Recommender):
     def _choose_grid(self):
         """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table, the rows of
         the open groups) in LDS, and a CU has 160 KB of it: stripes of <= 80 KB run two 16-wave workgroups per
-        CU (512 at a time), larger ones one (256).  The epoch is a whole number of such rounds, so the stripe
+        CU (512 at a time), larger ones - and all kernels for k > 128 or float64, which are built for 128 VGPRs -
+        one (256).  The epoch is a whole number of such rounds, so the stripe
         count is made 512 or 256 whenever the data allow it - 374 stripes of 86 KB cost ml25m two rounds, the
         second one a third full (18.4 ms; 256 stripes: 11.1 ms, profiles/).  User stripes: a quarter more than
         workgroups in flight (row locks are taken at random; measured best on MI355X).  Small inputs shrink both
@@ -282,7 +283,8 @@ class ExplicitMF(Recommender):
             n = int(self._d_samples.shape[0])
             U, I = self.n_users, self.n_items
             fits = lambda Gr_, Gc_, cap: lds_bytes(-(-I // Gc_), Gr_, k, esz, self.hot_batch) <= cap
-            if U >= 640 and I >= 512 and n >= 150 * 640 * 512 and fits(640, 512, 80 * 1024):
+            two_per_cu = esz == 4 and k <= 128     # wider rows / doubles run with 128 VGPRs: one workgroup per CU
+            if two_per_cu and U >= 640 and I >= 512 and n >= 150 * 640 * 512 and fits(640, 512, 80 * 1024):
                 Gr, Gc = 640, 512
             elif U >= 320 and I >= 256 and n >= 128 * 320 * 256 and fits(320, 256, 160 * 1024):
                 Gr, Gc = 320, 256

@@ -947,6 +947,11 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     PF_ADD(PF_BLOCK, b0, b4);
 }
 
+// Register budget: 8 waves per SIMD (64 VGPRs) lets two 16-wave workgroups share a CU, which is what k <= 128 in
+// fp32 wants; rows of more than 128 floats (or any doubles) spill at 64 VGPRs, and their stripes rarely leave
+// LDS for a second workgroup anyway: 4 waves per SIMD (128 VGPRs), one workgroup per CU.
+#define WAVES_PER_SIMD(T, KC) ((sizeof(T) == 8 || (KC) >= 3) ? 4 : 8)
+
 template <typename T, bool STAGE>
 __device__ __forceinline__ void stripe_load(const GridView &g, int32_t c, const T *Q, const T *b_i, int k, T *qs, T *bis)
 {
@@ -976,7 +981,7 @@ __device__ __forceinline__ void stripe_store(const GridView &g, int32_t c, T *Q,
 
 // schedule 0: one launch per anti-diagonal d; workgroup w does block (r0 + w, d - r0 - w)
 template <typename T, int KC, bool STAGE>
-__global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+__global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                       T beta1, T beta2, int variant, int k, int d, int r0,
                                                       LdsPlan<T> lp, SchedView s)
 {
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(1024, 8) void k_epoch_fixed(GridView g, T *P, T *Q,
 
 // schedule 1: persistent workgroups, column tenure + row locks
 template <typename T, int KC, bool STAGE, bool FAST>
-__global__ __launch_bounds__(1024, 8) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+__global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
