@@ -169,10 +169,10 @@ def main():
     m.init_params_device(args.seed)
     m._to_dev()
     n_train = int(m._d_samples.shape[0])
+    rmse0 = m.device_errors()                    # before any training (the warm-up epochs train too)
     for _ in range(args.warmup):
         m.run_epochs(1)
     grid.status()
-    rmse0 = m.device_errors()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()

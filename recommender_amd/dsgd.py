@@ -178,11 +178,11 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
         dist.all_reduce(acc)
         return float((acc[0] / acc[1]).sqrt()), float((acc[2] / acc[3]).sqrt())
 
+    rm0 = errors()                               # before any training (the warm-up epochs train too)
     for _ in range(args.warmup):
         ring_epoch(plan, rank, Q, b_i, compute, dist)
     for gr in grids:
         gr.status()
-    rm0 = errors()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
