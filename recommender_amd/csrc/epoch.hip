@@ -1086,11 +1086,12 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_free(Grid
                         while (r >= g.Gr) r -= g.Gr;
                         bool cand = base + lane < g.Gr && !row_done[r];
                         if (__ballot(cand) == 0) continue;
-                        // peek at the 64 lock words with one vector atomic (answered where the CAS is), then try
-                        // only rows that look free, starting at a pseudo-random one: workgroups that look at the
-                        // same stretch see the same free rows and would all race for the lowest
-                        int32_t *pw = cand ? &s.row_lock[r] : (int32_t *)(ctl + CTL_SINK + 2 * lane);
-                        const int32_t lockv = __hip_atomic_fetch_or(pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // peek at the 64 lock words with one coalesced agent-scope load (two cache lines from L2; as
+                        // a vector atomic this was 64 read-modify-writes on those lines per peek, and with short
+                        // blocks the lock search grew to 40% of the epoch), then try only rows that look free,
+                        // starting at a pseudo-random one: workgroups that look at the same stretch see the same
+                        // free rows and would all race for the lowest
+                        const int32_t lockv = __hip_atomic_load(&s.row_lock[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         cand = cand && lockv == 0;
                         unsigned long long mask = __ballot(cand);
                         int32_t skip = (int32_t)(mix32((uint32_t)(c * 977 + remain) + s.seed) %
