@@ -73,6 +73,19 @@ def _install_stubs():
             np.cumsum(np.bincount(rows, minlength=nrows), out=rp[1:])
             return cls(nrows, ncols, len(rows), rp, cols[order].astype(np.int32), vals[order])
 
+        # what ALSRecommender.als_step asks of the package (ALSRecommender.py:131-152)
+        def row_cs(self, r):
+            return self.colinds[self.rowptrs[r]:self.rowptrs[r + 1]]
+
+        def row(self, r):
+            out = np.zeros(self.ncols, dtype=self.values.dtype)
+            out[self.row_cs(r)] = self.values[self.rowptrs[r]:self.rowptrs[r + 1]]
+            return out
+
+        def transpose(self):
+            rows = np.repeat(np.arange(self.nrows), np.diff(self.rowptrs))
+            return CSR.from_coo(self.colinds, rows, self.values, shape=(self.ncols, self.nrows))
+
     csr.CSR = CSR
     sys.modules["csr"] = csr
     return CSR
@@ -411,6 +424,33 @@ def main():
     np.savez_compressed(os.path.join(OUT, "topn.npz"), P=Pp, Q=Qq, users=us, items=order.astype(np.int32),
                         scores=np.take_along_axis(dense, order, axis=1))
     print("predict/top-16: %d users x %d items" % dense.shape)
+
+    # ---------------------------------------------------------------- ALS: ExplicitMF.als_step / partial_train
+    # (ALSRecommender.py:118-183).  The class is imported whole; njit is the identity stub, so als_step is the
+    # reference's NumPy code run by the interpreter (numpy.linalg.solve, float64).
+    import ALSRecommender as refals
+    als_fn = refals.ExplicitMF.als_step
+    als_fn = getattr(als_fn, "__func__", als_fn)
+    out = {}
+    for k, U, I, n in ((8, 60, 45, 900), (40, 90, 70, 2500)):
+        rng = np.random.default_rng(1000 + k)
+        s3 = synth_ratings(rng, U, I, n)                       # unique (user, item) pairs, user-sorted
+        s3 = s3[s3[:, 0] != 7]                                 # a user without ratings
+        s3[:, 2] *= 2                                          # the 10-point scale of load_samples_from_npy (:103)
+        R = CSR.from_coo(s3[:, 0], s3[:, 1], s3[:, 2].astype(np.float64), shape=(U, I))
+        X0, Y0 = rng.random((U, k)), rng.random((I, k))
+        X1 = als_fn(X0.copy(), Y0, R, 0.05, "user")
+        Y1 = als_fn(Y0.copy(), X1, R, 0.1, "item")
+        Xn, Yn = X0.copy(), Y0.copy()
+        for _ in range(3):                                     # partial_train's loop (:167-180)
+            Xn = als_fn(Xn, Yn, R, 0.05, "user")
+            Yn = als_fn(Yn, Xn, R, 0.1, "item")
+        mse_fn = getattr(refals.ExplicitMF.mse, "__func__", refals.ExplicitMF.mse)
+        out.update({f"k{k}_samples": s3.astype(np.int32), f"k{k}_shape": np.array([U, I]), f"k{k}_X0": X0, f"k{k}_Y0": Y0,
+                    f"k{k}_X1": X1, f"k{k}_Y1": Y1, f"k{k}_X3": Xn, f"k{k}_Y3": Yn,
+                    f"k{k}_rmse3": np.float64(mse_fn(s3, Xn, Yn))})
+        print("als k=%d: rmse after 3 iterations %.4f" % (k, out[f"k{k}_rmse3"]))
+    np.savez_compressed(os.path.join(OUT, "als.npz"), user_reg=0.05, item_reg=0.1, **out)
     return 0
 
 

@@ -165,6 +165,51 @@ int FN(orc_sgd_hotbatch)(T *P, T *Q, T *b_u, T *b_i, T b, T *y, const T *z,
     return rc;
 }
 
+/* One half-step of alternating least squares (ALSRecommender.py:118-155, als_step): for every row r of
+ * the CSR (users when type == 'user', items - on the transposed CSR - when type == 'item') solve
+ *     (F_r^T F_r + lambda * (n_r + 1) * I) x = F_r^T v_r          (ALSRecommender.py:135-139 / :148-152)
+ * with F_r = fixed[col_inds of row r], v_r the row's values, n_r its length, and store x in latent[r].
+ * The reference calls numpy.linalg.solve (LU); the matrix is symmetric positive definite for lambda > 0,
+ * so this restatement factors it as L D L^T without pivoting.  A row without entries gives x = 0 (the
+ * reference solves lambda * I x = 0).  `fixed` is read only (the reference copies it first, :127). */
+int FN(orc_als_step)(T *latent, const T *fixed, const int64_t *row_ptrs, const int32_t *col_inds, const T *vals,
+                     int64_t n_rows, int32_t k, T lambda)
+{
+    T *A = (T *)malloc(sizeof(T) * (size_t)k * k), *bv = (T *)malloc(sizeof(T) * (size_t)k);
+    if (!A || !bv) { free(A); free(bv); return -1; }
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t lo = row_ptrs[r], hi = row_ptrs[r + 1];
+        for (int i = 0; i < k * k; ++i) A[i] = 0;
+        for (int i = 0; i < k; ++i) bv[i] = 0;
+        for (int64_t j = lo; j < hi; ++j) {
+            const T *f = fixed + (int64_t)col_inds[j] * k;
+            for (int a = 0; a < k; ++a) {
+                for (int c = 0; c <= a; ++c) A[a * k + c] += f[a] * f[c];
+                bv[a] += vals[j] * f[a];
+            }
+        }
+        for (int a = 0; a < k; ++a) A[a * k + a] += lambda * (T)(hi - lo + 1);
+        /* L D L^T in place (lower triangle), forward elimination of b alongside */
+        for (int j = 0; j < k; ++j) {
+            const T d = A[j * k + j];
+            if (!(d > 0)) { free(A); free(bv); return -3; }
+            for (int i = j + 1; i < k; ++i) {
+                const T lij = A[i * k + j] / d;
+                for (int c = j + 1; c <= i; ++c) A[i * k + c] -= lij * A[c * k + j];   /* column j still unscaled */
+                bv[i] -= lij * bv[j];
+            }
+            for (int i = j + 1; i < k; ++i) A[i * k + j] /= d;
+        }
+        for (int j = k - 1; j >= 0; --j) {
+            T x = bv[j] / A[j * k + j];
+            for (int i = j + 1; i < k; ++i) x -= A[i * k + j] * latent[r * (int64_t)k + i];
+            latent[r * (int64_t)k + j] = x;
+        }
+    }
+    free(A); free(bv);
+    return 0;
+}
+
 /* Exact RMSE of the numba_methods.py:94-100 predictor over ALL rows (mse2 with the
  * broken exact=True path repaired).  Accumulates in double. Global ids. */
 int FN(orc_rmse)(const T *P, const T *Q, const T *b_u, const T *b_i, T b, const T *y, const T *z,

@@ -149,6 +149,19 @@ def topn(P, Q, users, n, b_u=None, b_i=None, b=0.0):
     return items, scores
 
 
+def als_step(latent, fixed, row_ptrs, col_inds, vals, lam):
+    """In place: one ALS half-step (ALSRecommender.py:118-155) over the rows of the given CSR."""
+    suf, ct = _suf(latent.dtype)
+    _chk(latent, latent.dtype); _chk(fixed, latent.dtype)
+    rp = np.ascontiguousarray(row_ptrs, dtype=np.int64)
+    ci = np.ascontiguousarray(col_inds, dtype=np.int32)
+    v = np.ascontiguousarray(vals, dtype=latent.dtype)
+    rc = getattr(lib(), "orc_als_step_" + suf)(_p(latent), _p(fixed), _p(rp), _p(ci), _p(v), C.c_int64(latent.shape[0]),
+                                               C.c_int32(latent.shape[1]), ct(lam))
+    assert rc == 0, rc
+    return latent
+
+
 def bold_driver(train_rmse, alpha, previous):
     a, p = C.c_double(alpha), C.c_double(previous)
     lib().orc_bold_driver(C.c_double(train_rmse), C.byref(a), C.byref(p))

@@ -217,3 +217,44 @@ def test_topn_vs_reference_predict():
     items, scores = orc.topn(g["P"], g["Q"], g["users"], 16)
     assert np.array_equal(items, g["items"])
     assert np.allclose(scores, g["scores"], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ ALS: ALSRecommender.als_step
+def relerr(a, ref):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def _csr(rows, cols, vals, n_rows):
+    order = np.argsort(rows, kind="stable")
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_rows), out=rp[1:])
+    return rp, cols[order].astype(np.int32), vals[order]
+
+
+@pytest.mark.parametrize("k", [8, 40])
+def test_als_step_vs_reference(k):
+    """One user half-step, one item half-step and three full iterations of the reference's als_step
+    (ALSRecommender.py:118-183, float64, numpy.linalg.solve) against the oracle's L D L^T restatement."""
+    g = load("als.npz")
+    s = g[f"k{k}_samples"]
+    U, I = (int(v) for v in g[f"k{k}_shape"])
+    vals = s[:, 2].astype(np.float64)
+    by_user = _csr(s[:, 0], s[:, 1], vals, U)
+    by_item = _csr(s[:, 1], s[:, 0], vals, I)
+    ur, ir = float(g["user_reg"]), float(g["item_reg"])
+    X = orc.als_step(g[f"k{k}_X0"].copy(), g[f"k{k}_Y0"], *by_user, ur)
+    assert relerr(X, g[f"k{k}_X1"]) <= 1e-10
+    assert not X[7].any()                                    # the user without ratings
+    Y = orc.als_step(g[f"k{k}_Y0"].copy(), X, *by_item, ir)
+    assert relerr(Y, g[f"k{k}_Y1"]) <= 1e-10
+    X, Y = g[f"k{k}_X0"].copy(), g[f"k{k}_Y0"].copy()
+    for _ in range(3):
+        orc.als_step(X, Y, *by_user, ur)
+        orc.als_step(Y, X, *by_item, ir)
+    assert relerr(X, g[f"k{k}_X3"]) <= 1e-9 and relerr(Y, g[f"k{k}_Y3"]) <= 1e-9
+    pred = (X[s[:, 0]] * Y[s[:, 1]]).sum(1)
+    assert abs(np.sqrt(np.mean((s[:, 2] - pred) ** 2)) - float(g[f"k{k}_rmse3"])) < 1e-9
+    # float32 restatement: north_star's 1e-4 relative
+    X32 = orc.als_step(g[f"k{k}_X0"].astype(np.float32), g[f"k{k}_Y0"].astype(np.float32), by_user[0], by_user[1],
+                       by_user[2].astype(np.float32), ur)
+    assert relerr(X32, g[f"k{k}_X1"]) <= 1e-4
