@@ -182,6 +182,21 @@ int mfsgd_hip_epoch_f64(mfsgd_grid *g, int32_t k, double *P, double *Q, double *
                         int32_t iters, int32_t schedule, uint64_t seed, int32_t n_workgroups,
                         int32_t waves_per_wg, int32_t *order_log, void *stream);
 
+/* One half-step of alternating least squares: ExplicitMF.als_step (ALSRecommender.py:118-155).  For every row r
+ * of the CSR (row_ptrs[n_rows+1], col_inds, vals - the users' CSR for type == 'user', the transposed one for
+ * type == 'item', :131 / :142) solves (F^T F + lambda (n_r + 1) I) x = F^T v with F = fixed[col_inds of r]
+ * (:133-139) and writes x to latent[r]; a row without entries gets zeros.  `fixed` is only read (the reference
+ * copies it, :127).  `fixed` has n_cols rows, the CSR nnz entries: the kernel checks every row range and column
+ * index against them and reports a CSR that does not fit instead of reading outside the arrays.  k <= 128,
+ * lambda > 0 (the reference's defaults 0.0 make its solve singular for short rows).  Synchronises the stream
+ * before it returns (a broken CSR or a non-positive pivot is reported as an error). */
+int mfsgd_hip_als_step_f32(float *latent, const float *fixed, const int64_t *row_ptrs, const int32_t *col_inds,
+                           const float *vals, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t k, float lambda,
+                           void *stream);
+int mfsgd_hip_als_step_f64(double *latent, const double *fixed, const int64_t *row_ptrs, const int32_t *col_inds,
+                           const double *vals, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t k, double lambda,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,248 @@
+// als.hip - one half-step of alternating least squares for gfx950.
+//
+// Replaces ExplicitMF.als_step of the reference (ALSRecommender.py:118-155): for every row r of a CSR (users, or
+// items on the transposed CSR)
+//     (F_r^T F_r + lambda (n_r + 1) I) x = F_r^T v_r,   F_r = fixed[col_inds of r],  v_r = the row's ratings,
+// solved by the reference with numpy.linalg.solve, one row per Numba thread.
+//
+// Here one workgroup of 256 threads (a 16 x 16 arrangement) owns a row at a time (rows are handed out through a
+// global counter: row lengths differ by four orders of magnitude).  Thread (ty, tx) keeps the entries
+// A[ty + 16a][tx + 16b] of the k x k normal matrix in REGISTERS, cyclically, so that the work stays balanced
+// while the factorisation shrinks the active part:
+//   1. Gram: the row's factor rows are gathered 16 at a time into LDS; every thread adds the outer-product
+//      entries it owns (TS*TS FMAs for 2*TS LDS reads, TS = ceil(k/16)); threads ty == 0 also build F^T v.
+//   2. L D L^T without pivoting (the matrix is symmetric positive definite for lambda > 0), still in registers:
+//      step j publishes column j (and the j-th entry of the eliminated right-hand side) to LDS, one barrier, and
+//      everybody subtracts c_i c_l / d from what it owns.  Columns stay unscaled - no square roots, no second
+//      barrier - and the LDS copy of the columns is the factor the substitution needs.
+//   3. Back substitution by wave 0 on the LDS copy (column reads at an odd stride: conflict-free).
+// fp32 and fp64 share the code (the reference is float64; fp64 is what the 1e-9 parity test runs).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int ALS_CH = 16;       // factor rows gathered per step
+constexpr int ALS_THREADS = 256;
+
+struct AlsPlan {                 // byte offsets in dynamic LDS (multiples of 16)
+    uint32_t chunk, cvals, lmat, zfin, ctl, total;
+};
+
+template <typename T> AlsPlan als_plan(int k)
+{
+    auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t kp = (size_t)((k + 15) / 16) * 16, ld = kp + 1;
+    AlsPlan p{};
+    size_t o = 0;
+    p.chunk = (uint32_t)o; o = up(o + ALS_CH * kp * sizeof(T));
+    p.cvals = (uint32_t)o; o = up(o + ALS_CH * sizeof(T));
+    p.lmat = (uint32_t)o;  o = up(o + (size_t)k * ld * sizeof(T));
+    p.zfin = (uint32_t)o;  o = up(o + kp * sizeof(T));
+    p.ctl = (uint32_t)o;   o = up(o + 16);
+    p.total = (uint32_t)o;
+    return p;
+}
+
+template <typename T, int TS>
+__global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent, const T *__restrict__ fixed,
+                                                          const int64_t *__restrict__ row_ptrs,
+                                                          const int32_t *__restrict__ col_inds,
+                                                          const T *__restrict__ vals, int64_t n_rows, int64_t n_cols,
+                                                          int64_t nnz, int k, T lambda, int32_t *next_row,
+                                                          int32_t *err, AlsPlan lp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KP = 16 * TS, LD = KP + 1;
+    T *chunk = (T *)(smem + lp.chunk);    // [ALS_CH][KP], columns k..KP-1 are zero
+    T *cvals = (T *)(smem + lp.cvals);    // [ALS_CH]
+    T *lmat = (T *)(smem + lp.lmat);      // [k][LD]: row j holds column j of the factor, unscaled; [j][j] = d_j
+    T *zfin = (T *)(smem + lp.zfin);      // [KP]: eliminated right-hand side
+    int *ctl = (int *)(smem + lp.ctl);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    for (;;) {
+        __syncthreads();                  // the previous row's LDS is no longer read
+        if (tid == 0) ctl[0] = atomicAdd(next_row, 1);
+        __syncthreads();
+        const int64_t r = ctl[0];
+        if (r >= n_rows) break;
+        const int64_t lo = row_ptrs[r], hi = row_ptrs[r + 1];
+        const bool broken = lo < 0 || hi < lo || hi > nnz;     // a CSR that is not one: flag it, touch nothing of it
+        if (broken && tid == 0) atomicOr(err, 2);
+        if (hi == lo || broken) {         // lambda I x = 0 (ALSRecommender.py:135-139 with an empty fv)
+            for (int c = tid; c < k; c += ALS_THREADS) latent[r * k + c] = 0;
+            continue;
+        }
+        T acc[TS][TS], zacc[TS];
+#pragma unroll
+        for (int a = 0; a < TS; ++a) {
+            zacc[a] = 0;
+#pragma unroll
+            for (int b = 0; b < TS; ++b) acc[a][b] = 0;
+        }
+        // ---- 1. Gram matrix and right-hand side
+        for (int64_t base = lo; base < hi; base += ALS_CH) {
+            {
+                const int64_t t = base + ty;          // thread row ty of the 16 x 16 arrangement stages factor row ty
+                bool live = t < hi;
+                const int64_t col = live ? col_inds[t] : 0;
+                if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
+                const T *src = fixed + (live ? col : 0) * k;
+#pragma unroll
+                for (int b = 0; b < TS; ++b) {
+                    const int c = tx + 16 * b;
+                    chunk[ty * KP + c] = (live && c < k) ? src[c] : (T)0;
+                }
+                if (tx == 0) cvals[ty] = live ? vals[t] : (T)0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int m = 0; m < ALS_CH; ++m) {
+                T ai[TS], al[TS];
+#pragma unroll
+                for (int a = 0; a < TS; ++a) { ai[a] = chunk[m * KP + ty + 16 * a]; al[a] = chunk[m * KP + tx + 16 * a]; }
+#pragma unroll
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) acc[a][b] += ai[a] * al[b];
+                if (ty == 0) {
+                    const T v = cvals[m];
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) zacc[b] += v * al[b];
+                }
+            }
+            __syncthreads();
+        }
+        if (ty == tx) {
+            const T reg = lambda * (T)(hi - lo + 1);
+#pragma unroll
+            for (int a = 0; a < TS; ++a) acc[a][a] += reg;
+        }
+        // ---- 2. L D L^T in registers; column j and z_j go to LDS when they are final
+        bool bad = false;
+        for (int j = 0; j < k; ++j) {
+            const int jb = j >> 4, jt = j & 15;
+            if (tx == jt) {
+#pragma unroll
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b)
+                        if (b == jb) lmat[j * LD + ty + 16 * a] = acc[a][b];
+                if (ty == 0) {
+#pragma unroll
+                    for (int b = 0; b < TS; ++b)
+                        if (b == jb) zfin[j] = zacc[b];
+                }
+            }
+            __syncthreads();
+            const T d = lmat[j * LD + j];
+            bad = bad || !(d > 0);
+            const T inv = (T)1 / d;
+            T ci[TS], cl[TS];
+#pragma unroll
+            for (int a = 0; a < TS; ++a) { ci[a] = lmat[j * LD + ty + 16 * a] * inv; cl[a] = lmat[j * LD + tx + 16 * a]; }
+            // entries in rows or columns <= j are finished (already published) and never read again, so the update
+            // runs unguarded on everything a thread owns; the right-hand side is live and is guarded
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b < TS; ++b) acc[a][b] -= ci[a] * cl[b];
+            if (ty == 0) {
+                const T zj = zfin[j] * inv;
+#pragma unroll
+                for (int b = 0; b < TS; ++b)
+                    if (tx + 16 * b > j) zacc[b] -= cl[b] * zj;
+            }
+        }
+        if (bad && tid == 0) atomicOr(err, 1);
+        __syncthreads();
+        // ---- 3. back substitution: x_j = w_j / d_j, then w_l -= A[j][l] x_j for l < j (A[j][l] = column l at row j)
+        if (tid < 64) {
+            constexpr int WC = (KP + 63) / 64;
+            T w[WC], x[WC];
+#pragma unroll
+            for (int c = 0; c < WC; ++c) { const int l = tid + 64 * c; w[c] = l < k ? zfin[l] : (T)0; x[c] = 0; }
+            for (int j = k - 1; j >= 0; --j) {
+                T wj = 0;
+#pragma unroll
+                for (int c = 0; c < WC; ++c)
+                    if ((j >> 6) == c) wj = __shfl(w[c], j & 63, 64);
+                const T xj = wj / lmat[j * LD + j];
+#pragma unroll
+                for (int c = 0; c < WC; ++c) {
+                    const int l = tid + 64 * c;
+                    if (l == j) x[c] = xj;
+                    if (l < j) w[c] -= lmat[l * LD + j] * xj;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < WC; ++c) { const int l = tid + 64 * c; if (l < k) latent[r * k + l] = x[c]; }
+        }
+    }
+}
+
+template <typename T>
+int als_impl(T *latent, const T *fixed, const int64_t *row_ptrs, const int32_t *col_inds, const T *vals, int64_t n_rows,
+             int64_t n_cols, int64_t nnz, int32_t k, T lambda, void *stream)
+{
+    MF_ARG(n_rows >= 0 && n_rows < (int64_t)1 << 31, "als_step: n_rows=%lld out of range", (long long)n_rows);
+    if (n_rows == 0) return MFSGD_OK;
+    MF_ARG(latent && fixed && row_ptrs, "als_step: null pointer");
+    MF_ARG(n_cols >= 1 && nnz >= 0 && (nnz == 0 || (col_inds && vals)), "als_step: n_cols=%lld, nnz=%lld or null CSR arrays",
+           (long long)n_cols, (long long)nnz);
+    MF_ARG(k >= 1 && k <= 128, "als_step: k=%d outside [1,128]", k);
+    MF_ARG(lambda > 0, "als_step: lambda must be positive (the normal matrix has to be positive definite)");
+    hipStream_t st = as_stream(stream);
+    int32_t *work = nullptr;             // [0] next row, [1] error flag
+    MF_HIP(hipMalloc((void **)&work, 16));
+    struct Guard { int32_t *p; ~Guard() { (void)hipFree(p); } } guard{work};
+    MF_HIP(hipMemsetAsync(work, 0, 16, st));
+    const AlsPlan lp = als_plan<T>(k);
+    int dev = 0, n_cu = 256;
+    MF_HIP(hipGetDevice(&dev));
+    MF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lp.total)));
+    const int64_t n_wg = std::min<int64_t>(n_rows, (int64_t)n_cu * per_cu);
+#define MF_ALS(TS_)                                                                                                   \
+    case TS_: {                                                                                                       \
+        auto kern = k_als_rows<T, TS_>;                                                                               \
+        MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(ALS_THREADS), lp.total, st, latent, fixed, row_ptrs,      \
+                           col_inds, vals, n_rows, n_cols, nnz, (int)k, lambda, work, work + 1, lp);                               \
+        break;                                                                                                        \
+    }
+    switch ((k + 15) / 16) {
+        MF_ALS(1) MF_ALS(2) MF_ALS(3) MF_ALS(4) MF_ALS(5) MF_ALS(6) MF_ALS(7) MF_ALS(8)
+    }
+#undef MF_ALS
+    MF_LAUNCH_CHECK();
+    int32_t h[2] = {0, 0};
+    MF_HIP(hipMemcpyAsync(h, work, 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (h[1]) {
+        mfsgd_set_error("als_step: %s%s", (h[1] & 2) ? "row_ptrs / col_inds do not describe a CSR with n_cols columns and nnz entries; " : "",
+                        (h[1] & 1) ? "a normal matrix was not positive definite (pivot <= 0 or not finite)" : "");
+        return MFSGD_ERR_ARG;
+    }
+    return MFSGD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfsgd_hip_als_step_f32(float *latent, const float *fixed, const int64_t *row_ptrs, const int32_t *col_inds,
+                           const float *vals, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t k, float lambda,
+                           void *stream)
+{
+    return als_impl<float>(latent, fixed, row_ptrs, col_inds, vals, n_rows, n_cols, nnz, k, lambda, stream);
+}
+
+int mfsgd_hip_als_step_f64(double *latent, const double *fixed, const int64_t *row_ptrs, const int32_t *col_inds,
+                           const double *vals, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t k, double lambda,
+                           void *stream)
+{
+    return als_impl<double>(latent, fixed, row_ptrs, col_inds, vals, n_rows, n_cols, nnz, k, lambda, stream);
+}
+
+}  // extern "C"

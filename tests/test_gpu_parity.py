@@ -521,3 +521,100 @@ def test_topn_vs_reference_predict_and_oracle(ra, orc):
         ra.ExplicitMF.top_n([0], np.zeros((4, 8), np.float32), np.zeros((4, 8), np.float32), 4)
     with pytest.raises(IndexError):
         ra.ExplicitMF.top_n([9], g["P"][:5], g["Q"], 4)
+
+
+# ------------------------------------------------------------------ ALS half-step
+def _als_csr(rows, cols, vals, n_rows):
+    order = np.argsort(rows, kind="stable")
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_rows), out=rp[1:])
+    return rp, cols[order].astype(np.int32), vals[order]
+
+
+@pytest.mark.parametrize("k", [8, 40])
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-9), (np.float32, 1e-4)])
+def test_als_step_vs_reference(ra, k, dt, tol):
+    """ALSRecommender.ExplicitMF.als_step on the GPU against the reference's own als_step (golden als.npz:
+    float64, numpy.linalg.solve): one user half-step, one item half-step, three full iterations, the final RMSE."""
+    from recommender_amd.ALSRecommender import ExplicitMF as ALS
+    from recommender_amd.Recommender import CSRView
+    g = load("als.npz")
+    s = g[f"k{k}_samples"]
+    U, I = (int(v) for v in g[f"k{k}_shape"])
+    R = CSRView(*_als_csr(s[:, 0], s[:, 1], s[:, 2].astype(np.float64), U), U, I)
+    ur, ir = float(g["user_reg"]), float(g["item_reg"])
+    X0, Y0 = g[f"k{k}_X0"].astype(dt), g[f"k{k}_Y0"].astype(dt)
+    X = X0.copy()
+    ret = ALS.als_step(X, Y0, R, ur, "user")
+    assert ret is X and relerr(X, g[f"k{k}_X1"]) <= tol            # in place and returned, like the reference
+    assert not X[7].any()                                           # the user without ratings
+    Y = ALS.als_step(Y0.copy(), X, R, ir, "item")
+    assert relerr(Y, g[f"k{k}_Y1"]) <= tol
+    m = ALS(n_factors=k, item_reg=ir, user_reg=ur, dtype="float32" if dt == np.float32 else "float64")
+    m.n_users, m.n_items, m.samples, m.test_samples = U, I, s, s[:50]
+    m.set_ratings(s)
+    m.user_vecs, m.item_vecs = g[f"k{k}_X0"].copy(), g[f"k{k}_Y0"].copy()
+    m.partial_train(3)
+    assert relerr(m.user_vecs, g[f"k{k}_X3"]) <= 10 * tol and relerr(m.item_vecs, g[f"k{k}_Y3"]) <= 10 * tol
+    assert abs(ALS.mse(s, m.user_vecs, m.item_vecs) - float(g[f"k{k}_rmse3"])) < max(1e-9, 10 * tol)
+    assert abs(m.predict(3, 5) - m.user_vecs[3].dot(m.item_vecs[5])) < 1e-12
+
+
+@pytest.mark.parametrize("k,U,I,n", [(128, 300, 4000, 60000), (100, 500, 700, 30000), (16, 2000, 50, 20000), (1, 40, 30, 300)])
+def test_als_step_vs_oracle_shapes(ra, orc, k, U, I, n):
+    """Sizes the golden does not cover: k = 128 (the largest), k not a multiple of 16, rows of thousands of entries,
+    empty rows, k = 1.  fp64 against the fp64 oracle to 1e-9; fp32 against the fp64 oracle to 1e-3 (the normal
+    equations square the conditioning)."""
+    import torch
+    from recommender_amd import _abi
+    rng = np.random.default_rng(k + U)
+    s = _synthetic(rng, U, I, n)
+    s = s[s[:, 0] % 17 != 3]                                        # users without ratings
+    if k == 128:                                                    # one user who rated 3000 items
+        extra = np.column_stack([np.full(3000, 5), rng.permutation(I)[:3000], rng.integers(1, 11, 3000)])
+        s = np.concatenate([s[s[:, 0] != 5], extra]).astype(np.int32)
+    rp, ci, v = _als_csr(s[:, 0], s[:, 1], s[:, 2].astype(np.float64), U)
+    Y = rng.random((I, k))
+    ref = orc.als_step(np.zeros((U, k)), Y, rp, ci, v, 0.07)
+    for dt, tdt, fn, tol in ((np.float64, torch.float64, "mfsgd_hip_als_step_f64", 1e-9),
+                             (np.float32, torch.float32, "mfsgd_hip_als_step_f32", 1e-3)):
+        dX = torch.full((U, k), 7.0, dtype=tdt, device="cuda")
+        dY = torch.from_numpy(Y.astype(dt)).cuda()
+        d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v.astype(dt)).cuda()
+        assert int(d_rp[-1]) == len(ci) and int(d_ci.max()) < I          # the kernel trusts its CSR
+        _abi.check(getattr(_abi.lib(), fn)(_abi.ptr(dX), _abi.ptr(dY), _abi.ptr(d_rp), _abi.ptr(d_ci), _abi.ptr(d_v),
+                                           U, I, len(ci), k, 0.07, None))
+        torch.cuda.synchronize()
+        assert relerr(dX.cpu().numpy(), ref) <= tol, (dt, k)
+        assert not dX.cpu().numpy()[3].any()
+
+
+def test_als_step_rejects_bad_arguments(ra):
+    import torch
+    from recommender_amd import _abi
+    from recommender_amd.ALSRecommender import ExplicitMF as ALS
+    from recommender_amd.Recommender import CSRView
+    R = CSRView(np.array([0, 1, 2], np.int64), np.array([0, 1], np.int32), np.array([3.0, 4.0]), 2, 2)
+    with pytest.raises(Exception, match="positive"):
+        ALS.als_step(np.zeros((2, 4)), np.ones((2, 4)), R, 0.0, "user")       # the reference's default: singular
+    with pytest.raises(Exception, match="k="):
+        ALS.als_step(np.zeros((2, 129)), np.ones((2, 129)), R, 0.1, "user")
+    with pytest.raises(ValueError):
+        ALS.als_step(np.zeros((3, 4)), np.ones((2, 4)), R, 0.1, "user")
+    bad = CSRView(np.array([0, 1, 2], np.int64), np.array([0, 9], np.int32), np.array([3.0, 4.0]), 2, 2)
+    with pytest.raises(IndexError):
+        ALS.als_step(np.zeros((2, 4)), np.ones((2, 4)), bad, 0.1, "user")
+    assert _abi.lib().mfsgd_hip_als_step_f32(None, None, None, None, None, 0, 1, 0, 4, 0.1, None) == 0   # no rows: no-op
+    # a CSR that does not fit its arrays is reported, not followed (the kernel checks ranges before it reads)
+    lat, fix = torch.zeros(2, 4, device="cuda"), torch.ones(2, 4, device="cuda")
+    rp = torch.tensor([0, 1, 5], dtype=torch.int64, device="cuda")           # row 1 claims 4 entries, there are 2
+    ci = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    v = torch.tensor([3.0, 4.0], device="cuda")
+    rc = _abi.lib().mfsgd_hip_als_step_f32(_abi.ptr(lat), _abi.ptr(fix), _abi.ptr(rp), _abi.ptr(ci), _abi.ptr(v),
+                                           2, 2, 2, 4, 0.1, None)
+    assert rc != 0 and b"CSR" in _abi.lib().mfsgd_last_error()
+    ci2 = torch.tensor([0, 7], dtype=torch.int32, device="cuda")             # column 7 of a 2-row `fixed`
+    rp2 = torch.tensor([0, 1, 2], dtype=torch.int64, device="cuda")
+    rc = _abi.lib().mfsgd_hip_als_step_f32(_abi.ptr(lat), _abi.ptr(fix), _abi.ptr(rp2), _abi.ptr(ci2), _abi.ptr(v),
+                                           2, 2, 2, 4, 0.1, None)
+    assert rc != 0 and b"CSR" in _abi.lib().mfsgd_last_error()
