@@ -9,8 +9,9 @@
 // global counter: row lengths differ by four orders of magnitude).  Thread (ty, tx) keeps the entries
 // A[ty + 16a][tx + 16b] of the k x k normal matrix in REGISTERS, cyclically, so that the work stays balanced
 // while the factorisation shrinks the active part:
-//   1. Gram: the row's factor rows are gathered 16 at a time into LDS; every thread adds the outer-product
-//      entries it owns (TS*TS FMAs for 2*TS LDS reads, TS = ceil(k/16)); threads ty == 0 also build F^T v.
+//   1. Gram: the row's factor rows are gathered 16 at a time into LDS (the next 16 are in flight meanwhile); every
+//      thread adds the outer-product entries it owns (TS*TS FMAs for 2*TS LDS reads, TS = ceil(k/16)); threads
+//      ty == 0 also build F^T v.
 //   2. L D L^T without pivoting (the matrix is symmetric positive definite for lambda > 0), still in registers:
 //      step j publishes column j (and the j-th entry of the eliminated right-hand side) to LDS, one barrier, and
 //      everybody subtracts c_i c_l / d from what it owns.  Columns stay unscaled - no square roots, no second
@@ -35,10 +36,13 @@ template <typename T> AlsPlan als_plan(int k)
     const size_t kp = (size_t)((k + 15) / 16) * 16, ld = kp + 1;
     AlsPlan p{};
     size_t o = 0;
-    p.chunk = (uint32_t)o; o = up(o + ALS_CH * kp * sizeof(T));
-    p.cvals = (uint32_t)o; o = up(o + ALS_CH * sizeof(T));
-    p.lmat = (uint32_t)o;  o = up(o + (size_t)k * ld * sizeof(T));
-    p.zfin = (uint32_t)o;  o = up(o + kp * sizeof(T));
+    // the gather buffers are only alive during the Gram phase, the factor only after it: they share one region
+    const size_t stage = up(2 * ALS_CH * kp * sizeof(T)) + up(2 * ALS_CH * sizeof(T));
+    p.chunk = (uint32_t)o;
+    p.cvals = (uint32_t)(o + up(2 * ALS_CH * kp * sizeof(T)));
+    p.lmat = (uint32_t)o;
+    o = up(o + std::max(stage, (size_t)k * ld * sizeof(T)));
+    p.zfin = (uint32_t)o;  o = up(o + 2 * kp * sizeof(T));   // eliminated right-hand side, reciprocal pivots
     p.ctl = (uint32_t)o;   o = up(o + 16);
     p.total = (uint32_t)o;
     return p;
@@ -54,10 +58,11 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = 16 * TS, LD = KP + 1;
-    T *chunk = (T *)(smem + lp.chunk);    // [ALS_CH][KP], columns k..KP-1 are zero
-    T *cvals = (T *)(smem + lp.cvals);    // [ALS_CH]
+    T *chunk = (T *)(smem + lp.chunk);    // [2][ALS_CH][KP], columns k..KP-1 are zero
+    T *cvals = (T *)(smem + lp.cvals);    // [2][ALS_CH]
     T *lmat = (T *)(smem + lp.lmat);      // [k][LD]: row j holds column j of the factor, unscaled; [j][j] = d_j
     T *zfin = (T *)(smem + lp.zfin);      // [KP]: eliminated right-hand side
+    T *dinv = zfin + KP;                  // [KP]: 1 / d_j
     int *ctl = (int *)(smem + lp.ctl);
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     for (;;) {
@@ -80,37 +85,51 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
             for (int b = 0; b < TS; ++b) acc[a][b] = 0;
         }
-        // ---- 1. Gram matrix and right-hand side
-        for (int64_t base = lo; base < hi; base += ALS_CH) {
-            {
-                const int64_t t = base + ty;          // thread row ty of the 16 x 16 arrangement stages factor row ty
-                bool live = t < hi;
-                const int64_t col = live ? col_inds[t] : 0;
-                if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
-                const T *src = fixed + (live ? col : 0) * k;
+        // ---- 1. Gram matrix and right-hand side.  The gather of chunk c+1 (HBM latency) is in flight while chunk c
+        // is multiplied out of LDS; two LDS buffers, one barrier per chunk.
+        T pre[TS], prev = 0;
+        auto fetch = [&](int64_t base) {          // thread row ty of the 16 x 16 arrangement fetches factor row ty
+            const int64_t t = base + ty;
+            bool live = t < hi;
+            const int64_t col = live ? col_inds[t] : 0;
+            if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
+            const T *src = fixed + (live ? col : 0) * k;
 #pragma unroll
-                for (int b = 0; b < TS; ++b) {
-                    const int c = tx + 16 * b;
-                    chunk[ty * KP + c] = (live && c < k) ? src[c] : (T)0;
-                }
-                if (tx == 0) cvals[ty] = live ? vals[t] : (T)0;
+            for (int b = 0; b < TS; ++b) {
+                const int c = tx + 16 * b;
+                pre[b] = (live && c < k) ? src[c] : (T)0;
             }
-            __syncthreads();
+            prev = (live && tx == 0) ? vals[t] : (T)0;
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int b = 0; b < TS; ++b) chunk[buf * (ALS_CH * KP) + ty * KP + tx + 16 * b] = pre[b];
+            if (tx == 0) cvals[buf * ALS_CH + ty] = prev;
+        };
+        fetch(lo);
+        commit(0);
+        __syncthreads();
+        int buf = 0;
+        for (int64_t base = lo; base < hi; base += ALS_CH, buf ^= 1) {
+            const bool more = base + ALS_CH < hi;
+            if (more) fetch(base + ALS_CH);
+            const T *ch = chunk + buf * (ALS_CH * KP);
 #pragma unroll 4
             for (int m = 0; m < ALS_CH; ++m) {
                 T ai[TS], al[TS];
 #pragma unroll
-                for (int a = 0; a < TS; ++a) { ai[a] = chunk[m * KP + ty + 16 * a]; al[a] = chunk[m * KP + tx + 16 * a]; }
+                for (int a = 0; a < TS; ++a) { ai[a] = ch[m * KP + ty + 16 * a]; al[a] = ch[m * KP + tx + 16 * a]; }
 #pragma unroll
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
                     for (int b = 0; b < TS; ++b) acc[a][b] += ai[a] * al[b];
                 if (ty == 0) {
-                    const T v = cvals[m];
+                    const T v = cvals[buf * ALS_CH + m];
 #pragma unroll
                     for (int b = 0; b < TS; ++b) zacc[b] += v * al[b];
                 }
             }
+            if (more) commit(buf ^ 1);
             __syncthreads();
         }
         if (ty == tx) {
@@ -118,40 +137,40 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
             for (int a = 0; a < TS; ++a) acc[a][a] += reg;
         }
-        // ---- 2. L D L^T in registers; column j and z_j go to LDS when they are final
+        // ---- 2. L D L^T in registers; column j and z_j go to LDS when they are final.  The loop over the 16-column
+        // panels is unrolled, so the panel index jb is a constant in the body: the published column is a fixed
+        // register (no select chain), and tiles above or left of the panel - finished rows and columns - are skipped.
         bool bad = false;
-        for (int j = 0; j < k; ++j) {
-            const int jb = j >> 4, jt = j & 15;
-            if (tx == jt) {
 #pragma unroll
-                for (int a = 0; a < TS; ++a)
+        for (int jb = 0; jb < TS; ++jb) {
+            for (int jt = 0; jt < 16; ++jt) {
+                const int j = 16 * jb + jt;
+                if (j >= k) break;
+                if (tx == jt) {
 #pragma unroll
-                    for (int b = 0; b < TS; ++b)
-                        if (b == jb) lmat[j * LD + ty + 16 * a] = acc[a][b];
-                if (ty == 0) {
-#pragma unroll
-                    for (int b = 0; b < TS; ++b)
-                        if (b == jb) zfin[j] = zacc[b];
+                    for (int a = jb; a < TS; ++a) lmat[j * LD + ty + 16 * a] = acc[a][jb];
+                    if (ty == 0) zfin[j] = zacc[jb];
                 }
-            }
-            __syncthreads();
-            const T d = lmat[j * LD + j];
-            bad = bad || !(d > 0);
-            const T inv = (T)1 / d;
-            T ci[TS], cl[TS];
+                __syncthreads();
+                const T d = lmat[j * LD + j];
+                bad = bad || !(d > 0);
+                const T inv = (T)1 / d;
+                if (tid == 0) dinv[j] = inv;
+                T ci[TS], cl[TS];
 #pragma unroll
-            for (int a = 0; a < TS; ++a) { ci[a] = lmat[j * LD + ty + 16 * a] * inv; cl[a] = lmat[j * LD + tx + 16 * a]; }
-            // entries in rows or columns <= j are finished (already published) and never read again, so the update
-            // runs unguarded on everything a thread owns; the right-hand side is live and is guarded
+                for (int a = jb; a < TS; ++a) { ci[a] = lmat[j * LD + ty + 16 * a] * inv; cl[a] = lmat[j * LD + tx + 16 * a]; }
+                // inside the panel's own tiles, entries in rows or columns <= j are finished and never read again, so
+                // the update runs unguarded there; the right-hand side is live and is guarded
 #pragma unroll
-            for (int a = 0; a < TS; ++a)
+                for (int a = jb; a < TS; ++a)
 #pragma unroll
-                for (int b = 0; b < TS; ++b) acc[a][b] -= ci[a] * cl[b];
-            if (ty == 0) {
-                const T zj = zfin[j] * inv;
+                    for (int b = jb; b < TS; ++b) acc[a][b] -= ci[a] * cl[b];
+                if (ty == 0) {
+                    const T zj = zfin[j] * inv;
 #pragma unroll
-                for (int b = 0; b < TS; ++b)
-                    if (tx + 16 * b > j) zacc[b] -= cl[b] * zj;
+                    for (int b = jb; b < TS; ++b)
+                        if (tx + 16 * b > j) zacc[b] -= cl[b] * zj;
+                }
             }
         }
         if (bad && tid == 0) atomicOr(err, 1);
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
                 for (int c = 0; c < WC; ++c)
                     if ((j >> 6) == c) wj = __shfl(w[c], j & 63, 64);
-                const T xj = wj / lmat[j * LD + j];
+                const T xj = wj * dinv[j];
 #pragma unroll
                 for (int c = 0; c < WC; ++c) {
                     const int l = tid + 64 * c;
