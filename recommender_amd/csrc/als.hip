@@ -8,7 +8,8 @@
 // Here one workgroup of 256 threads (a 16 x 16 arrangement) owns a row at a time (rows are handed out through a
 // global counter: row lengths differ by four orders of magnitude).  Thread (ty, tx) keeps the entries
 // A[ty + 16a][tx + 16b] of the k x k normal matrix in REGISTERS, cyclically, so that the work stays balanced
-// while the factorisation shrinks the active part:
+// while the factorisation shrinks the active part; only the tiles b <= a (on and below the diagonal) are ever
+// computed - the matrix is symmetric and the elimination reads columns from the diagonal down:
 //   1. Gram: the row's factor rows are gathered 16 at a time into LDS (the next 16 are in flight meanwhile); every
 //      thread adds the outer-product entries it owns (TS*TS FMAs for 2*TS LDS reads, TS = ceil(k/16)); threads
 //      ty == 0 also build F^T v.
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
-                    for (int b = 0; b < TS; ++b) acc[a][b] += ai[a] * al[b];
+                    for (int b = 0; b <= a; ++b) acc[a][b] += ai[a] * al[b];   // tiles b > a lie above the diagonal
                 if (ty == 0) {
                     const T v = cvals[buf * ALS_CH + m];
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
                 for (int a = jb; a < TS; ++a)
 #pragma unroll
-                    for (int b = jb; b < TS; ++b) acc[a][b] -= ci[a] * cl[b];
+                    for (int b = jb; b <= a; ++b) acc[a][b] -= ci[a] * cl[b];
                 if (ty == 0) {
                     const T zj = zfin[j] * inv;
 #pragma unroll
