@@ -10,9 +10,11 @@
 // A[ty + 16a][tx + 16b] of the k x k normal matrix in REGISTERS, cyclically, so that the work stays balanced
 // while the factorisation shrinks the active part; only the tiles b <= a (on and below the diagonal) are ever
 // computed - the matrix is symmetric and the elimination reads columns from the diagonal down:
-//   1. Gram: the row's factor rows are gathered 16 at a time into LDS (the next 16 are in flight meanwhile); every
-//      thread adds the outer-product entries it owns (TS*TS FMAs for 2*TS LDS reads, TS = ceil(k/16)); threads
-//      ty == 0 also build F^T v.
+//   1. Gram: the row's factor rows are gathered 16 at a time into LDS (the next 16 are in flight meanwhile).
+//      fp32 with k > 64: the four waves multiply the 32 x 32 tiles on and below the diagonal on the matrix cores
+//      (v_mfma_f32_32x32x2_f32) and hand the result to the cyclic register layout through LDS.  Otherwise every
+//      thread adds the outer-product entries it owns (vector FMAs, 2*TS LDS reads per chunk row, TS = ceil(k/16)).
+//      F^T v is built alongside.
 //   2. L D L^T without pivoting (the matrix is symmetric positive definite for lambda > 0), still in registers:
 //      step j publishes column j (and the j-th entry of the eliminated right-hand side) to LDS, one barrier, and
 //      everybody subtracts c_i c_l / d from what it owns.  Columns stay unscaled - no square roots, no second
@@ -24,17 +26,21 @@
 
 namespace {
 
-constexpr int ALS_CH = 16;       // factor rows gathered per step
+#ifndef MFSGD_ALS_CH
+#define MFSGD_ALS_CH 16
+#endif
+constexpr int ALS_CH = MFSGD_ALS_CH;   // factor rows gathered per step (a multiple of 16)
+constexpr int ALS_RPT = ALS_CH / 16;   // of which every thread row of the 16 x 16 arrangement fetches this many
 constexpr int ALS_THREADS = 256;
 
 struct AlsPlan {                 // byte offsets in dynamic LDS (multiples of 16)
     uint32_t chunk, cvals, lmat, zfin, ctl, total;
 };
 
-template <typename T> AlsPlan als_plan(int k)
+template <typename T> AlsPlan als_plan(int k, int ts)
 {
     auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t kp = (size_t)((k + 15) / 16) * 16, ld = kp + 1;
+    const size_t kp = (size_t)ts * 16, ld = kp + 1;
     AlsPlan p{};
     size_t o = 0;
     // the gather buffers are only alive during the Gram phase, the factor only after it: they share one region
@@ -42,14 +48,20 @@ template <typename T> AlsPlan als_plan(int k)
     p.chunk = (uint32_t)o;
     p.cvals = (uint32_t)(o + up(2 * ALS_CH * kp * sizeof(T)));
     p.lmat = (uint32_t)o;
-    o = up(o + std::max(stage, (size_t)k * ld * sizeof(T)));
+    o = up(o + std::max(stage, kp * ld * sizeof(T)));   // kp rows: the matrix-core path parks the whole padded Gram matrix here
     p.zfin = (uint32_t)o;  o = up(o + 2 * kp * sizeof(T));   // eliminated right-hand side, reciprocal pivots
     p.ctl = (uint32_t)o;   o = up(o + 16);
     p.total = (uint32_t)o;
     return p;
 }
 
-template <typename T, int TS>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MFMA (fp32, TS even): the Gram matrix is accumulated on the matrix cores (v_mfma_f32_32x32x2_f32) in 32 x 32
+// tiles, the tiles on and below the diagonal dealt round-robin to the four waves, and handed over to the cyclic
+// register layout of the elimination through LDS.  Otherwise (fp64, or k <= 64 where the padding to 32 costs more
+// than it saves) the threads accumulate their own entries with vector FMAs.
+template <typename T, int TS, bool MFMA>
 __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent, const T *__restrict__ fixed,
                                                           const int64_t *__restrict__ row_ptrs,
                                                           const int32_t *__restrict__ col_inds,
@@ -88,33 +100,78 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         }
         // ---- 1. Gram matrix and right-hand side.  The gather of chunk c+1 (HBM latency) is in flight while chunk c
         // is multiplied out of LDS; two LDS buffers, one barrier per chunk.
-        T pre[TS], prev = 0;
-        auto fetch = [&](int64_t base) {          // thread row ty of the 16 x 16 arrangement fetches factor row ty
-            const int64_t t = base + ty;
-            bool live = t < hi;
-            const int64_t col = live ? col_inds[t] : 0;
-            if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
-            const T *src = fixed + (live ? col : 0) * k;
+        T pre[ALS_RPT][TS], prev[ALS_RPT];
+        auto fetch = [&](int64_t base) {          // thread row ty of the 16 x 16 arrangement fetches factor rows ty, ty + 16, ..
 #pragma unroll
-            for (int b = 0; b < TS; ++b) {
-                const int c = tx + 16 * b;
-                pre[b] = (live && c < k) ? src[c] : (T)0;
+            for (int q = 0; q < ALS_RPT; ++q) {
+                const int64_t t = base + ty + 16 * q;
+                bool live = t < hi;
+                const int64_t col = live ? col_inds[t] : 0;
+                if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
+                const T *src = fixed + (live ? col : 0) * k;
+#pragma unroll
+                for (int b = 0; b < TS; ++b) {
+                    const int c = tx + 16 * b;
+                    pre[q][b] = (live && c < k) ? src[c] : (T)0;
+                }
+                prev[q] = (live && tx == 0) ? vals[t] : (T)0;
             }
-            prev = (live && tx == 0) ? vals[t] : (T)0;
         };
         auto commit = [&](int buf) {
 #pragma unroll
-            for (int b = 0; b < TS; ++b) chunk[buf * (ALS_CH * KP) + ty * KP + tx + 16 * b] = pre[b];
-            if (tx == 0) cvals[buf * ALS_CH + ty] = prev;
+            for (int q = 0; q < ALS_RPT; ++q) {
+#pragma unroll
+                for (int b = 0; b < TS; ++b) chunk[buf * (ALS_CH * KP) + (ty + 16 * q) * KP + tx + 16 * b] = pre[q][b];
+                if (tx == 0) cvals[buf * ALS_CH + ty + 16 * q] = prev[q];
+            }
         };
         fetch(lo);
         commit(0);
         __syncthreads();
         int buf = 0;
+        // matrix-core path: tile t = wave + 4 s of the lower triangle, t = ti (ti + 1) / 2 + tj
+        constexpr int NT = TS / 2, NTL = NT * (NT + 1) / 2, SLOTS = MFMA ? (NTL + 3) / 4 : 1;
+        f32x16 macc[SLOTS];
+        int offa[SLOTS], offb[SLOTS];
+        bool own[SLOTS];
+        T zt = 0;
+        if (MFMA) {
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int t = wave + 4 * sl;
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                own[sl] = t < NTL;
+                offa[sl] = own[sl] ? 32 * ti : 0;
+                offb[sl] = own[sl] ? 32 * (t - ti * (ti + 1) / 2) : 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) macc[sl][e] = 0;
+            }
+        }
         for (int64_t base = lo; base < hi; base += ALS_CH, buf ^= 1) {
             const bool more = base + ALS_CH < hi;
             if (more) fetch(base + ALS_CH);
             const T *ch = chunk + buf * (ALS_CH * KP);
+            if constexpr (MFMA) {
+                const int colm = tid & 31, kh = (tid >> 5) & 1;   // MFMA operand coordinates of this lane
+#pragma unroll
+                for (int kk = 0; kk < ALS_CH; kk += 2) {
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        // no `if (own[sl])` here: a branch per MFMA puts every one of them behind its own LDS round
+                        // trip (seen in the ISA).  A wave without a tile for this slot multiplies tile (0, 0) again
+                        // on its own SIMD - nobody waits for it - and drops the result at the hand-over.
+                        const float av = ch[(kk + kh) * KP + offa[sl] + colm];
+                        const float bv = ch[(kk + kh) * KP + offb[sl] + colm];
+                        macc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, macc[sl], 0, 0, 0);
+                    }
+                }
+                if (tid < KP) {
+#pragma unroll
+                    for (int m = 0; m < ALS_CH; ++m) zt += cvals[buf * ALS_CH + m] * ch[m * KP + tid];
+                }
+            } else {
 #pragma unroll 4
             for (int m = 0; m < ALS_CH; ++m) {
                 T ai[TS], al[TS];
@@ -130,8 +187,32 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
                     for (int b = 0; b < TS; ++b) zacc[b] += v * al[b];
                 }
             }
+            }
             if (more) commit(buf ^ 1);
             __syncthreads();
+        }
+        if constexpr (MFMA) {
+            // hand-over: MFMA tile layout (lane = column, 16 rows in registers) -> LDS -> the threads' cyclic entries
+            const int colm = tid & 31, kh = (tid >> 5) & 1;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                if (own[sl]) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        lmat[(offa[sl] + 8 * (e / 4) + 4 * kh + (e % 4)) * LD + offb[sl] + colm] = macc[sl][e];
+                }
+            }
+            if (tid < KP) zfin[tid] = zt;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) acc[a][b] = lmat[(ty + 16 * a) * LD + tx + 16 * b];
+            if (ty == 0) {
+#pragma unroll
+                for (int b = 0; b < TS; ++b) zacc[b] = zfin[tx + 16 * b];
+            }
+            __syncthreads();          // the elimination reuses this memory for the factor
         }
         if (ty == tx) {
             const T reg = lambda * (T)(hi - lo + 1);
@@ -217,22 +298,33 @@ int als_impl(T *latent, const T *fixed, const int64_t *row_ptrs, const int32_t *
     MF_HIP(hipMalloc((void **)&work, 16));
     struct Guard { int32_t *p; ~Guard() { (void)hipFree(p); } } guard{work};
     MF_HIP(hipMemsetAsync(work, 0, 16, st));
-    const AlsPlan lp = als_plan<T>(k);
+    // fp32 above k = 64: Gram on the matrix cores, which wants the padded size to be a multiple of 32
+    const bool mfma = sizeof(T) == 4 && k > 64;
+    const int ts = mfma ? 2 * ((k + 31) / 32) : (k + 15) / 16;
+    const AlsPlan lp = als_plan<T>(k, ts);
     int dev = 0, n_cu = 256;
     MF_HIP(hipGetDevice(&dev));
     MF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lp.total)));
     const int64_t n_wg = std::min<int64_t>(n_rows, (int64_t)n_cu * per_cu);
-#define MF_ALS(TS_)                                                                                                   \
-    case TS_: {                                                                                                       \
-        auto kern = k_als_rows<T, TS_>;                                                                               \
+#define MF_ALS(TS_, M_)                                                                                               \
+    {                                                                                                                 \
+        auto kern = k_als_rows<T, TS_, M_>;                                                                           \
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));   \
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(ALS_THREADS), lp.total, st, latent, fixed, row_ptrs,      \
-                           col_inds, vals, n_rows, n_cols, nnz, (int)k, lambda, work, work + 1, lp);                               \
+                           col_inds, vals, n_rows, n_cols, nnz, (int)k, lambda, work, work + 1, lp);                  \
         break;                                                                                                        \
     }
-    switch ((k + 15) / 16) {
-        MF_ALS(1) MF_ALS(2) MF_ALS(3) MF_ALS(4) MF_ALS(5) MF_ALS(6) MF_ALS(7) MF_ALS(8)
+    if constexpr (sizeof(T) == 4) {
+        switch (mfma ? 100 + ts : ts) {
+            case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
+            case 106: MF_ALS(6, true) case 108: MF_ALS(8, true)
+        }
+    } else {
+        switch (ts) {
+            case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
+            case 5: MF_ALS(5, false) case 6: MF_ALS(6, false) case 7: MF_ALS(7, false) case 8: MF_ALS(8, false)
+        }
     }
 #undef MF_ALS
     MF_LAUNCH_CHECK();

@@ -560,10 +560,12 @@ def test_als_step_vs_reference(ra, k, dt, tol):
     assert abs(m.predict(3, 5) - m.user_vecs[3].dot(m.item_vecs[5])) < 1e-12
 
 
-@pytest.mark.parametrize("k,U,I,n", [(128, 300, 4000, 60000), (100, 500, 700, 30000), (16, 2000, 50, 20000), (1, 40, 30, 300)])
+@pytest.mark.parametrize("k,U,I,n", [(128, 300, 4000, 60000), (100, 500, 700, 30000), (80, 400, 600, 30000),
+                                     (65, 100, 300, 8000), (64, 300, 300, 20000), (16, 2000, 50, 20000), (1, 40, 30, 300)])
 def test_als_step_vs_oracle_shapes(ra, orc, k, U, I, n):
-    """Sizes the golden does not cover: k = 128 (the largest), k not a multiple of 16, rows of thousands of entries,
-    empty rows, k = 1.  fp64 against the fp64 oracle to 1e-9; fp32 against the fp64 oracle to 1e-3 (the normal
+    """Sizes the golden does not cover: k = 128 (the largest), k not a multiple of 16, both matrix-core variants of
+    the fp32 kernel (65 <= k <= 96 and 97 <= k <= 128) and the largest vector one (k = 64), rows of thousands of
+    entries, empty rows, k = 1.  fp64 against the fp64 oracle to 1e-9; fp32 against the fp64 oracle to 1e-3 (the normal
     equations square the conditioning)."""
     import torch
     from recommender_amd import _abi
