@@ -32,6 +32,9 @@ namespace {
 constexpr int ALS_CH = MFSGD_ALS_CH;   // factor rows gathered per step (a multiple of 16)
 constexpr int ALS_RPT = ALS_CH / 16;   // of which every thread row of the 16 x 16 arrangement fetches this many
 constexpr int ALS_THREADS = 256;
+#ifndef MFSGD_ALS_EXP
+#define MFSGD_ALS_EXP 0   // timing experiments (results wrong on purpose): 1 = no elimination, 2 = no substitution
+#endif
 
 struct AlsPlan {                 // byte offsets in dynamic LDS (multiples of 16)
     uint32_t chunk, cvals, lmat, zfin, ctl, total;
@@ -56,6 +59,23 @@ template <typename T> AlsPlan als_plan(int k, int ts)
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// value of `v` in lane `lane` (wave-uniform index): v_readlane, no LDS crossbar
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// 1 / d for the pivots: the hardware reciprocal (1 ulp) in fp32, a division in fp64
+__device__ __forceinline__ float pivot_inv(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ double pivot_inv(double d) { return 1.0 / d; }
 
 // MFMA (fp32, TS even): the Gram matrix is accumulated on the matrix cores (v_mfma_f32_32x32x2_f32) in 32 x 32
 // tiles, the tiles on and below the diagonal dealt round-robin to the four waves, and handed over to the cyclic
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         for (int jb = 0; jb < TS; ++jb) {
             for (int jt = 0; jt < 16; ++jt) {
                 const int j = 16 * jb + jt;
-                if (j >= k) break;
+                if (j >= ((MFSGD_ALS_EXP & 1) ? 0 : k)) break;
                 if (tx == jt) {
 #pragma unroll
                     for (int a = jb; a < TS; ++a) lmat[j * LD + ty + 16 * a] = acc[a][jb];
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
                 __syncthreads();
                 const T d = lmat[j * LD + j];
                 bad = bad || !(d > 0);
-                const T inv = (T)1 / d;
+                const T inv = pivot_inv(d);
                 if (tid == 0) dinv[j] = inv;
                 T ci[TS], cl[TS];
 #pragma unroll
@@ -259,21 +279,41 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         __syncthreads();
         // ---- 3. back substitution: x_j = w_j / d_j, then w_l -= A[j][l] x_j for l < j (A[j][l] = column l at row j)
         if (tid < 64) {
+            // One wave, k dependent steps: everything a step needs except x_j itself is fetched a step ahead
+            // (column j of the transposed factor, a strided LDS read), w_j and 1/d_j come out of registers with
+            // v_readlane (j is wave-uniform), so a step is a handful of ALU instructions, not an LDS round trip.
             constexpr int WC = (KP + 63) / 64;
-            T w[WC], x[WC];
+            T w[WC], x[WC], dv[WC], col[WC];
 #pragma unroll
-            for (int c = 0; c < WC; ++c) { const int l = tid + 64 * c; w[c] = l < k ? zfin[l] : (T)0; x[c] = 0; }
-            for (int j = k - 1; j >= 0; --j) {
-                T wj = 0;
+            for (int c = 0; c < WC; ++c) {
+                const int l = tid + 64 * c;
+                w[c] = l < k ? zfin[l] : (T)0;
+                dv[c] = l < k ? dinv[l] : (T)0;
+                x[c] = 0;
+            }
+            const int k_sub = (MFSGD_ALS_EXP & 2) ? 0 : k;
+            auto column = [&](int j, T (&out)[WC]) {      // A[j][l] for this lane's l < j: column l at row j
+#pragma unroll
+                for (int c = 0; c < WC; ++c) {
+                    const int l = tid + 64 * c;
+                    out[c] = (j >= 0 && l < j) ? lmat[l * LD + j] : (T)0;
+                }
+            };
+            column(k_sub - 1, col);
+            for (int j = k_sub - 1; j >= 0; --j) {
+                T nxt[WC];
+                column(j - 1, nxt);
+                T wj = 0, dj = 0;
 #pragma unroll
                 for (int c = 0; c < WC; ++c)
-                    if ((j >> 6) == c) wj = __shfl(w[c], j & 63, 64);
-                const T xj = wj * dinv[j];
+                    if ((j >> 6) == c) { wj = lane_bcast(w[c], j & 63); dj = lane_bcast(dv[c], j & 63); }
+                const T xj = wj * dj;
 #pragma unroll
                 for (int c = 0; c < WC; ++c) {
                     const int l = tid + 64 * c;
                     if (l == j) x[c] = xj;
-                    if (l < j) w[c] -= lmat[l * LD + j] * xj;
+                    w[c] -= col[c] * xj;                  // col is zero for l >= j
+                    col[c] = nxt[c];
                 }
             }
 #pragma unroll
