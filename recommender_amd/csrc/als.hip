@@ -279,7 +279,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         __syncthreads();
         // ---- 3. back substitution: x_j = w_j / d_j, then w_l -= A[j][l] x_j for l < j (A[j][l] = column l at row j)
         if (tid < 64) {
-            // One wave, k dependent steps: everything a step needs except x_j itself is fetched a step ahead
+            // One wave, k dependent steps: everything a step needs except x_j itself is fetched four steps ahead
             // (column j of the transposed factor, a strided LDS read), w_j and 1/d_j come out of registers with
             // v_readlane (j is wave-uniform), so a step is a handful of ALU instructions, not an LDS round trip.
             constexpr int WC = (KP + 63) / 64;
@@ -299,21 +299,29 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
                     out[c] = (j >= 0 && l < j) ? lmat[l * LD + j] : (T)0;
                 }
             };
-            column(k_sub - 1, col);
-            for (int j = k_sub - 1; j >= 0; --j) {
-                T nxt[WC];
-                column(j - 1, nxt);
-                T wj = 0, dj = 0;
+            constexpr int AHEAD = 4;                      // columns in flight (LDS latency / step time)
+            T ring[AHEAD][WC];
 #pragma unroll
-                for (int c = 0; c < WC; ++c)
-                    if ((j >> 6) == c) { wj = lane_bcast(w[c], j & 63); dj = lane_bcast(dv[c], j & 63); }
-                const T xj = wj * dj;
+            for (int q = 0; q < AHEAD; ++q) column(k_sub - 1 - q, ring[q]);
+            for (int j0 = k_sub - 1; j0 >= 0; j0 -= AHEAD) {
 #pragma unroll
-                for (int c = 0; c < WC; ++c) {
-                    const int l = tid + 64 * c;
-                    if (l == j) x[c] = xj;
-                    w[c] -= col[c] * xj;                  // col is zero for l >= j
-                    col[c] = nxt[c];
+                for (int q = 0; q < AHEAD; ++q) {
+                    const int j = j0 - q;
+                    if (j < 0) break;                     // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < WC; ++c) col[c] = ring[q][c];
+                    column(j - AHEAD, ring[q]);
+                    T wj = 0, dj = 0;
+#pragma unroll
+                    for (int c = 0; c < WC; ++c)
+                        if ((j >> 6) == c) { wj = lane_bcast(w[c], j & 63); dj = lane_bcast(dv[c], j & 63); }
+                    const T xj = wj * dj;
+#pragma unroll
+                    for (int c = 0; c < WC; ++c) {
+                        const int l = tid + 64 * c;
+                        if (l == j) x[c] = xj;
+                        w[c] -= col[c] * xj;              // col is zero for l >= j
+                    }
                 }
             }
 #pragma unroll
