@@ -292,7 +292,11 @@ class ExplicitMF(Recommender):
                 ring = (2 * self.hot_batch + 1) * k * esz if self.hot_batch > 1 else 0    # LDS rows of the open groups
                 ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
                 Gc_min = -(-I // ibp_max)
-                Gc, Gr = min(I, 512), min(U, 640)
+                # user stripes: a quarter more than workgroups in flight - 512 only if two fit a CU (checked below)
+                Gc = min(I, 512)
+                ibp0 = -(-I // max(Gc, Gc_min))
+                two = two_per_cu and lds_bytes(ibp0, 640, k, esz, self.hot_batch) <= 80 * 1024
+                Gr = min(U, 640 if two else 320)      # Yahoo shape, k=256: 640 -> 320 rows took 276 -> 201 ms
                 want = max(1.0, n / 128.0)
                 if Gr * Gc > want:
                     f = (want / (Gr * Gc)) ** 0.5
