@@ -137,7 +137,8 @@ def main():
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dsgd = bool(os.environ.get("MFSGD_FORCE_DSGD"))   # rehearsal: run the multi-GPU leg (RCCL plumbing) with one rank
+    if world > 1 or force_dsgd:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -148,7 +149,7 @@ def main():
         train = train[:, [1, 0, 2]].contiguous(); test = test[:, [1, 0, 2]].contiguous(); U, I = I, U
     if args.k:
         k = args.k
-    if world > 1:
+    if world > 1 or force_dsgd:
         from recommender_amd import dsgd
         return dsgd.bench_main(args, rank, world, (train, test, U, I, k), bytes_per_update, HBM_PEAK,
                                (ALPHA, BETA1, BETA2))
