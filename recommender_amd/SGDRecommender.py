@@ -270,7 +270,9 @@ class ExplicitMF(Recommender):
         """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table, the rows of
         the open groups) in LDS, and a CU has 160 KB of it: stripes of <= 80 KB run two 16-wave workgroups per
         CU (512 at a time), larger ones - and all kernels for k > 128 or float64, which are built for 128 VGPRs -
-        one (256).  The epoch is a whole number of such rounds, so the stripe
+        one (256).  With the grouped updates (hot_batch > 1) one workgroup per CU on the 128-VGPR build is also the
+        faster choice for k <= 128 (netflix shape: 32.3 ms against 33.7 ms), so 512 stripes are only chosen for the
+        sequential order, whose item chains are shorter in narrower stripes.  The epoch is a whole number of such rounds, so the stripe
         count is made 512 or 256 whenever the data allow it - 374 stripes of 86 KB cost ml25m two rounds, the
         second one a third full (18.4 ms; 256 stripes: 11.1 ms, profiles/).  User stripes: a quarter more than
         workgroups in flight (row locks are taken at random; measured best on MI355X).  Small inputs shrink both
@@ -284,10 +286,11 @@ class ExplicitMF(Recommender):
             U, I = self.n_users, self.n_items
             fits = lambda Gr_, Gc_, cap: lds_bytes(-(-I // Gc_), Gr_, k, esz, self.hot_batch) <= cap
             two_per_cu = esz == 4 and k <= 128     # wider rows / doubles run with 128 VGPRs: one workgroup per CU
-            if two_per_cu and U >= 640 and I >= 512 and n >= 150 * 640 * 512 and fits(640, 512, 80 * 1024):
-                Gr, Gc = 640, 512
-            elif U >= 320 and I >= 256 and n >= 128 * 320 * 256 and fits(320, 256, 160 * 1024):
-                Gr, Gc = 320, 256
+            if (self.hot_batch == 1 and two_per_cu and U >= 640 and I >= 512 and n >= 150 * 640 * 512
+                    and fits(640, 512, 80 * 1024)):
+                Gr, Gc = 640, 512      # sequential order inside a block: the chains want the narrower stripes
+            elif U >= 288 and I >= 256 and n >= 128 * 288 * 256 and fits(288, 256, 160 * 1024):
+                Gr, Gc = 288, 256      # one workgroup per CU, 128 VGPRs (swept 256..320 rows: flat, 272-288 best)
             else:
                 ring = (2 * self.hot_batch + 1) * k * esz if self.hot_batch > 1 else 0    # LDS rows of the open groups
                 ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))

@@ -1012,8 +1012,11 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
 }
 
 // schedule 1: persistent workgroups, column tenure + row locks
-template <typename T, int KC, bool STAGE, bool FAST>
-__global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
+// WPS = waves per SIMD the kernel is built for: 8 (64 VGPRs) lets two 16-wave workgroups share a CU, 4 (128 VGPRs)
+// is one workgroup per CU without the register squeeze - 3-8% faster whenever the grid has no more stripes than
+// the GPU has CUs (measured: netflix 33.7 -> 32.3 ms, frozen 44.0 -> 40.7 ms), so both are built for k <= 128 fp32.
+template <typename T, int KC, bool STAGE, bool FAST, int WPS>
+__global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1527,15 +1530,21 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         return MFSGD_OK;
     }
     const bool fast = k == 64 * KC && z == nullptr && gv.user_unique;
-    auto kern = fast ? k_epoch_free<T, KC, STAGE, true> : k_epoch_free<T, KC, STAGE, false>;
+    hipDeviceProp_t prop;
+    MF_HIP(hipGetDeviceProperties(&prop, G->device));
+    // two workgroups per CU only pay when there are more stripes than CUs and two stripes fit the LDS of one
+    constexpr bool can8 = WAVES_PER_SIMD(T, KC) == 8;
+    const bool wps8 = can8 && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
+    auto kern = fast ? k_epoch_free<T, KC, STAGE, true, 4> : k_epoch_free<T, KC, STAGE, false, 4>;
+    if constexpr (can8) {
+        if (wps8) kern = fast ? k_epoch_free<T, KC, STAGE, true, 8> : k_epoch_free<T, KC, STAGE, false, 8>;
+    }
     const char *dbg_env = getenv("MFSGD_DEBUG_FLAGS");
     const int32_t dbg = dbg_env ? atoi(dbg_env) : 0;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
-    hipDeviceProp_t prop;
-    MF_HIP(hipGetDeviceProperties(&prop, G->device));
     if (n_wg <= 0) {
         int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
-        per_cu = std::max(1, std::min(per_cu, std::max(1, 32 / waves)));
+        per_cu = std::max(1, std::min(per_cu, std::max(1, (wps8 ? 32 : 16) / waves)));
         n_wg = prop.multiProcessorCount * per_cu;
     }
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
