@@ -87,8 +87,8 @@ def lds_bytes(ibp, Gr, k, esz, group=1):
     o = up(o + words * esz)
     o = up(o + rows * k * esz)
     o = up(o + 16 * 8)
-    o = up(o + 514 * 4)
-    o = up(o + 514 * 4)
+    o = up(o + 1026 * 4)
+    o = up(o + 1026 * 4)
     return o
 
 

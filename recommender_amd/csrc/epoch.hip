@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
     uint32_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, ring_ui, rt_u, rt_t, total;
 };
-constexpr int RT_CAP = 512;   // runs per block the LDS run table takes
+constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
 
 // Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
 // the row its predecessor wrote.  Through the LDS ticket that hand-off costs a poll, a row read, the update and
@@ -507,6 +507,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             const size_t own = (size_t)il * k, alt = (size_t)((hot.p + ((size_t)2 << hot.shift) * k) - qs);  // one base: DS addressing
             const size_t mine = par ? alt : own, other = par ? own : alt;
             T *bmine = par ? &hot.s[2] : &bis[il], *bother = par ? &bis[il] : &hot.s[2];
+            PF_T(g0);
             T bi;
             for (int spins = 0;; ++spins) {
                 const int32_t seen = __hip_atomic_load(hot.st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -521,6 +522,8 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                 if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
                 __builtin_amdgcn_s_sleep(TICKET_NAP);
             }
+            PF_T(g1);
+            PF_ADD(29, g0, g1);
             T part = 0;
 #pragma unroll
             for (int c = 0; c < KC; ++c) part += q[c] * (FAST ? p[c] : p[c] + zz[c]);
@@ -574,6 +577,9 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __hip_atomic_store(sink_ptr(hot.st, ctl, lane), grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            PF_T(g2);
+            PF_ADD(30, g1, g2);
+            PF_INC(31, 1);
             bu += alpha * (e - beta1 * bu);
             PF_INC(PF_RATINGS, 1);
             continue;
@@ -1712,7 +1718,8 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
     {
         static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
                                               "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure", "poll|ahead=0", "n|ahead=0",
-                                              "sum ahead", "poll|ahead=1", "n|ahead=1"};
+                                              "sum ahead", "poll|ahead=1", "n|ahead=1", nullptr, nullptr, nullptr, nullptr, nullptr,
+                                              nullptr, nullptr, nullptr, nullptr, nullptr, "hot: version wait", "hot: update+close", "hot: ratings"};
         unsigned long long pf[PF_SLOTS];
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));

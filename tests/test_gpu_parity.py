@@ -247,7 +247,7 @@ def _synthetic(rng, U, I, n, lead=False):
     (128, 3000, 900, 200000, (64, 16), 8),
     (64, 2000, 5000, 150000, (32, 32), 16),
     (200, 700, 400, 40000, (16, 8), 8),
-    (64, 3000, 600, 120000, (4, 12), 16),      # 750 users per stripe: blocks longer than the LDS run table (chunks)
+    (64, 6000, 600, 250000, (4, 8), 16),       # 1500 users per stripe: blocks longer than the LDS run table (chunks)
 ])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
 def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode, hot_batch=1, schedule=1,
@@ -328,7 +328,7 @@ def test_grouped_hot_item_updates_replay_on_oracle(ra, orc, group):
     f = test_free_block_schedule_replays_on_oracle
     f(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_batch=group)
     f(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_batch=group)
-    f(ra, orc, 64, 3000, 600, 120000, (4, 12), 16, "frozen", hot_batch=group)
+    f(ra, orc, 64, 6000, 600, 250000, (4, 8), 16, "frozen", hot_batch=group)
     f(ra, orc, 200, 700, 400, 40000, (16, 8), 8, "frozen", hot_batch=group)
     f(ra, orc, 32, 500, 300, 30000, (8, 6), 4, "none", hot_batch=group, schedule=0)
 
