@@ -307,6 +307,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
     uint32_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, ring_ui, rt_u, rt_t, total;
 };
+#ifndef MFSGD_HEADS
+#define MFSGD_HEADS 3     // runs a wave is bound to: the one it walks + this many - 1 whose head loads are in flight
+#endif
 constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
 
 // Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
@@ -903,11 +906,21 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, nxt);
         int32_t jf = claim();
         index(jf, x);
+#if MFSGD_HEADS == 4   // experiment: one more run in flight (the 128-VGPR build has the registers)
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far);
+        RunHead<T, KC> far2;
+        int32_t jg = claim();
+        index(jg, x);
+#endif
         PF_T(b1);
         PF_ADD(PF_PROLOGUE, b0, b1);
         while (j < nr) {
             PF_T(i0);
+#if MFSGD_HEADS == 4
+            load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far2);
+#else
             load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far);
+#endif
             PF_T(i1);
             PF_ADD(PF_ISSUE, i0, i1);
             walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
@@ -916,8 +929,15 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             nxt = far;
             j = jn;
             jn = jf;
+#if MFSGD_HEADS == 4
+            far = far2;
+            jf = jg;
+            jg = claim();
+            index(jg, x);
+#else
             jf = claim();
             index(jf, x);
+#endif
         }
     }
     if (lo + RT_CAP < run_hi) {   // another chunk follows: its table replaces this one
