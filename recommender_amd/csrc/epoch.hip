@@ -307,9 +307,6 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
     uint32_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, ring_ui, rt_u, rt_t, total;
 };
-#ifndef MFSGD_HEADS
-#define MFSGD_HEADS 3     // runs a wave is bound to: the one it walks + this many - 1 whose head loads are in flight
-#endif
 constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
 
 // Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
@@ -896,49 +893,38 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
         };
-        RunHead<T, KC> cur, nxt, far;
+        // The run loop is unrolled three times and the three heads change roles instead of being copied
+        // (cur = nxt; nxt = far cost ~16 v_mov per run): the kernel is bound by VALU issue,
+        // and this alone took the netflix epoch from 31.9 to 28.7 ms.
+        RunHead<T, KC> h0, h1, h2;
         RunIdx x;
-        int32_t j = claim();
-        index(j, x);
-        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, cur);
-        int32_t jn = claim();
-        index(jn, x);
-        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, nxt);
-        int32_t jf = claim();
-        index(jf, x);
-#if MFSGD_HEADS == 4   // experiment: one more run in flight (the 128-VGPR build has the registers)
-        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far);
-        RunHead<T, KC> far2;
-        int32_t jg = claim();
-        index(jg, x);
-#endif
+        int32_t j0 = claim();
+        index(j0, x);
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, h0);
+        int32_t j1 = claim();
+        index(j1, x);
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, h1);
+        int32_t j2 = claim();
+        index(j2, x);
         PF_T(b1);
         PF_ADD(PF_PROLOGUE, b0, b1);
-        while (j < nr) {
-            PF_T(i0);
-#if MFSGD_HEADS == 4
-            load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far2);
-#else
-            load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, far);
-#endif
-            PF_T(i1);
-            PF_ADD(PF_ISSUE, i0, i1);
-            walk_run<T, KC, STAGE, FAST, HOT>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                              tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
-            cur = nxt;
-            nxt = far;
-            j = jn;
-            jn = jf;
-#if MFSGD_HEADS == 4
-            far = far2;
-            jf = jg;
-            jg = claim();
-            index(jg, x);
-#else
-            jf = claim();
-            index(jf, x);
-#endif
+        // one step: the head of the run claimed last goes into the free slot LOAD, the run in WALK is walked,
+        // the next run is claimed (only now: DESIGN.md section 3.1) and its index words are read
+#define MF_STEP(WALK, LOAD, JW, JN)                                                                                     \
+        if (JW >= nr) break;                                                                                          \
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
+        walk_run<T, KC, STAGE, FAST, HOT>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,     \
+                                          tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);           \
+        JN = claim();                                                                                                 \
+        index(JN, x);
+        for (;;) {
+            int32_t ja, jb, jc;
+            MF_STEP(h0, h2, j0, ja)
+            MF_STEP(h1, h0, j1, jb)
+            MF_STEP(h2, h1, j2, jc)
+            j0 = ja; j1 = jb; j2 = jc;
         }
+#undef MF_STEP
     }
     if (lo + RT_CAP < run_hi) {   // another chunk follows: its table replaces this one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
