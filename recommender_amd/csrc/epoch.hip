@@ -469,12 +469,13 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     PF_T(w1);
     PF_ADD(PF_HEADWAIT, w0, w1);
     PF_INC(PF_RUNS, 1);
-    T p[KC], zz[KC], q[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) { p[c] = h.p[c]; zz[c] = h.zz[c]; }
-    T bu = h.bu;
-    int32_t m_item = h.m_item, m_tick = h.m_tick;
-    float m_val = h.m_val;
+    // the walk works on the head's own registers (no copies at entry: every VALU instruction counts)
+    T (&p)[KC] = h.p;
+    T (&zz)[KC] = h.zz;
+    T q[KC];
+    T &bu = h.bu;
+    int32_t &m_item = h.m_item, &m_tick = h.m_tick;
+    float &m_val = h.m_val;
     T *prow = P + (int64_t)u * k;
     for (int32_t t = t0; t < t1; ++t) {
         const int32_t slot = (t - t0) & 63;
