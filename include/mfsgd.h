@@ -70,6 +70,22 @@ int mfsgd_hip_rmse_f64(const double *P, const double *Q, const double *b_u, cons
                        const int64_t *row_ptrs, const int32_t *col_inds, int32_t k, int32_t implicit,
                        double *d_partials, double *d_sse, void *stream);
 
+/* Allocation-free variant of mfsgd_hip_rmse_f32.  It has NO counterpart in the reference; it exists for callers
+ * that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it):
+ * the per-block partial sums that mfsgd_hip_rmse_f32 takes as the caller's d_partials workspace live in a
+ * file-scope __device__ array of the library instead (16 KB per GPU, held until the process ends).  The call
+ * itself performs no hipMalloc / hipFree and calls no allocating routine; inputs and d_sse are still the
+ * caller's.  Same kernels, same fixed reduction order: *d_sse is bit-identical to mfsgd_hip_rmse_f32's.
+ * Limits: n <= MFSGD_RMSE_NOALLOC_MAX_N ratings per call, k <= MFSGD_RMSE_NOALLOC_MAX_K; beyond them the call
+ * fails with MFSGD_ERR_ARG and touches nothing.  Every call on one GPU shares that GPU's array: calls that
+ * overlap on one GPU (two streams, two threads) race - serialise them.  Asynchronous on `stream`. */
+#define MFSGD_RMSE_NOALLOC_MAX_N ((int64_t)2147483647)
+#define MFSGD_RMSE_NOALLOC_MAX_K 4096
+int mfsgd_hip_rmse_noalloc_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
+                               const float *y, const float *z, const int32_t *samples, int64_t n, int32_t stride,
+                               const int64_t *row_ptrs, const int32_t *col_inds, int32_t k, int32_t implicit,
+                               double *d_sse, void *stream);
+
 /* z[u] = sum_{j in N(u)} y[j] / (sqrt|N(u)| + plus_one)  (numba_methods.py:14-16, :36 for plus_one=1) */
 int mfsgd_hip_implicit_z_f32(const float *y, const int64_t *row_ptrs, const int32_t *col_inds,
                              int64_t n_users, int32_t k, int32_t plus_one, float *z, void *stream);
@@ -126,7 +142,6 @@ typedef struct {
     int32_t order;        /* 0 = reference order inside a block, 1 = user-sorted inside a block */
     int32_t user_unique;  /* 1 if no user has two runs in one block */
     int64_t max_block, max_col_nnz, max_row_nnz;
-    int32_t n_served;     /* item stripes whose most rated item gets a server wave in the free-block kernel */
     int32_t n_hot_stripes; /* item stripes whose most rated item carries >= 1/16 of the stripe's ratings (user_unique grids) */
 } mfsgd_grid_info;
 

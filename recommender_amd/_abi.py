@@ -22,7 +22,7 @@ class GridInfo(C.Structure):
                 ("Gr", c_i32), ("Gc", c_i32), ("ubp", c_i32), ("ibp", c_i32),
                 ("order", c_i32), ("user_unique", c_i32),
                 ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64),
-                ("n_served", c_i32), ("n_hot_stripes", c_i32)]
+                ("n_hot_stripes", c_i32)]
 
 
 def _sig_sgd(ct):
@@ -49,6 +49,7 @@ SIGNATURES = {
     "mfsgd_rmse_partials": (c_i64, [c_i64]),
     "mfsgd_hip_rmse_f32": (C.c_int, _sig_rmse(c_f32)),
     "mfsgd_hip_rmse_f64": (C.c_int, _sig_rmse(c_f64)),
+    "mfsgd_hip_rmse_noalloc_f32": (C.c_int, _sig_rmse(c_f32)[:14] + [c_vp, c_vp]),
     "mfsgd_hip_implicit_z_f32": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "mfsgd_hip_implicit_z_f64": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "mfsgd_hip_remap": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_vp]),

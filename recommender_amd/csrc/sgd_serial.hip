@@ -7,6 +7,32 @@
 // whole pass, so no two threads ever touch the same word and the only exchange per rating is the k-wide
 // dot (wave DPP sum + 4-word LDS combine, fixed order).
 #include "common.h"
+#include <mutex>
+
+// ---- scratch of the allocation-free entry point (mfsgd_hip_rmse_noalloc_f32): the per-block partial sums
+// live in a file-scope device array instead of a caller workspace.  In host code `scratch` is only a stand-in
+// for the symbol, never a device address: the address is resolved once per device with hipGetSymbolAddress
+// (each GPU holds its own copy of the array) and only that pointer is handed to kernels.
+constexpr int SCRATCH_DOUBLES = 2048;   // = RMSE_BLOCKS (static_assert below)
+static __device__ __align__(256) double scratch[SCRATCH_DOUBLES];   // 16 KB per GPU, held until the process ends
+constexpr int MAX_DEVICES = 64;
+static double *g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_ptr(double **out)
+{
+    int dev = 0;
+    MF_HIP(hipGetDevice(&dev));
+    MF_ARG(dev >= 0 && dev < MAX_DEVICES, "rmse_noalloc: device ordinal %d outside [0,%d)", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        MF_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));   // with `dev` current: this device's copy
+        g_scratch_ptr[dev] = (double *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MFSGD_OK;
+}
 
 namespace {
 
@@ -118,6 +144,7 @@ __global__ __launch_bounds__(SERIAL_THREADS) void k_sgd_serial(
 
 constexpr int RMSE_THREADS = 256;
 constexpr int RMSE_BLOCKS = 2048;
+static_assert(RMSE_BLOCKS <= SCRATCH_DOUBLES, "the no-alloc scratch must hold one partial per block");
 
 template <typename T>
 __global__ __launch_bounds__(RMSE_THREADS) void k_rmse(
@@ -259,6 +286,24 @@ int mfsgd_hip_sgd_f64(double *P, double *Q, double *b_u, double *b_i, double b, 
 }
 
 int64_t mfsgd_rmse_partials(int64_t) { return RMSE_BLOCKS; }
+
+int mfsgd_hip_rmse_noalloc_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
+                               const float *y, const float *z, const int32_t *samples, int64_t n, int32_t stride,
+                               const int64_t *row_ptrs, const int32_t *col_inds, int32_t k, int32_t implicit,
+                               double *d_sse, void *stream)
+{
+    MF_ARG(n <= MFSGD_RMSE_NOALLOC_MAX_N, "rmse_noalloc: n=%lld exceeds the limit of %lld ratings per call",
+           (long long)n, (long long)MFSGD_RMSE_NOALLOC_MAX_N);
+    MF_ARG(k <= MFSGD_RMSE_NOALLOC_MAX_K, "rmse_noalloc: k=%d exceeds the limit of %d factors", k,
+           MFSGD_RMSE_NOALLOC_MAX_K);
+    double *partials = nullptr;
+    const int rc = scratch_ptr(&partials);
+    if (rc) return rc;
+    // every block overwrites its own partial and k_sum_partials reads only the blocks of THIS call:
+    // nothing left behind by an earlier (larger) call is ever read, so nothing has to be cleared
+    return rmse_impl<float>(P, Q, b_u, b_i, b, y, z, samples, n, stride, row_ptrs, col_inds, k, implicit, partials,
+                            d_sse, stream);
+}
 
 int mfsgd_hip_rmse_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const float *y,
                        const float *z, const int32_t *samples, int64_t n, int32_t stride, const int64_t *row_ptrs,
