@@ -75,8 +75,8 @@ def lds_bytes(ibp, Gr, k, esz, group=1):
     """LDS a free-block workgroup needs for item stripes of `ibp` items (lds_plan in csrc/epoch.hip, kept in
     step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes)."""
     up = lambda x: (x + 15) & ~15
-    rows = max(16, 2 * group + 1 if group > 1 else 0)
-    words = max(32, 2 * group + 4 if group > 1 else 0)
+    rows = 2 * group + 1 if group > 1 else 0
+    words = 2 * group + 4 if group > 1 else 0
     o = up((16 + 128) * 4)
     o = up(o + ibp * 4)
     o = up(o + Gr)
@@ -86,7 +86,6 @@ def lds_bytes(ibp, Gr, k, esz, group=1):
     o = up(o + 16 * 4)
     o = up(o + words * esz)
     o = up(o + rows * k * esz)
-    o = up(o + 16 * 8)
     o = up(o + 1026 * 4)
     o = up(o + 1026 * 4)
     return o
@@ -121,8 +120,8 @@ class Grid:
         _abi.check(_abi.lib().mfsgd_grid_col_hot(self.handle, out.ctypes.data_as(_abi.c_vp), _abi.stream_ptr()))
         return out
 
-    def export(self):
-        """Host copies of the grid arrays (tests: bucketing must be bit-exact)."""
+    def export_device(self):
+        """Device copies of the grid arrays (mfsgd_grid_export): dict of ROCm tensors."""
         torch = _abi.torch_mod()
         i = self.info
         nb, n, nr = i.Gr * i.Gc, int(i.n), int(i.n_runs)
@@ -136,9 +135,12 @@ class Grid:
                                                 ("blk_run_ptr", "run_start", "run_user", "item", "val", "tick")),
                                                 _abi.stream_ptr()))
         torch.cuda.synchronize()
-        out = {k: v.cpu().numpy() for k, v in t.items()}
-        out["run_user"], out["item"], out["val"], out["tick"] = out["run_user"][:nr], out["item"][:n], out["val"][:n], out["tick"][:n]
-        return out
+        t["run_user"], t["item"], t["val"], t["tick"] = t["run_user"][:nr], t["item"][:n], t["val"][:n], t["tick"][:n]
+        return t
+
+    def export(self):
+        """Host copies of the grid arrays (tests: bucketing must be bit-exact)."""
+        return {k: v.cpu().numpy() for k, v in self.export_device().items()}
 
     def __del__(self):
         try:
@@ -162,11 +164,12 @@ class ExplicitMF(Recommender):
                  dtype="float32",        # device arithmetic of the FPSGD path ("float32" | "float64")
                  grid=None,              # (Gr, Gc) of the throughput grid; None = chosen from the shapes
                  exact_errors=True,      # geterrors over all rows (the reference subsamples, mse2)
-                 hot_batch=None,         # throughput mode only: each stripe's most rated item is updated in groups
-                                         # of this size (power of two <= 64; include/mfsgd.h
-                                         # mfsgd_grid_set_hot_batch).  1 = the reference's sequential order inside
-                                         # a block; None = 8 (same RMSE, measured; 1.3x the throughput on
-                                         # Netflix-shaped data).  deterministic=True always runs sequentially.
+                 hot_batch=None,         # None / 1 = the reference's sequential order inside a block (the default).
+                                         # 2..64 (power of two) is an explicit opt-in, throughput mode only: each
+                                         # stripe's most rated item is then updated in groups of this size
+                                         # (include/mfsgd.h mfsgd_grid_set_hot_batch; RMSE within 0.002 of the
+                                         # sequential order, tests/test_gpu_baseline_configs.py).
+                                         # deterministic=True always runs sequentially.
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -181,7 +184,7 @@ class ExplicitMF(Recommender):
         self.dtype = dtype
         self.grid_shape = grid
         self.exact_errors = exact_errors
-        self.hot_batch = 1 if deterministic else (8 if hot_batch is None else int(hot_batch))
+        self.hot_batch = 1 if (deterministic or hot_batch is None) else int(hot_batch)
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -488,9 +491,12 @@ class ExplicitMF(Recommender):
         self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp))
 
     def _apply_renumbering(self, row_index, col_index):
+        """Remap ids by `row_index` / `col_index` (current id -> new id).  self.row_perm / col_perm always map the
+        ORIGINAL ids to the current ones: a second renumbering composes with the first, so that
+        unrandomize_samples undoes all of them (SGDRecommender.py:270-284 undoes its single shuffle)."""
         torch = _abi.torch_mod()
-        self.col_perm, self.row_perm = np.asarray(col_index).astype(np.int32), np.asarray(row_index).astype(np.int32)
-        d_rp, d_cp = _abi.to_device(self.row_perm, "int32"), _abi.to_device(self.col_perm, "int32")
+        step_c, step_r = np.asarray(col_index).astype(np.int32), np.asarray(row_index).astype(np.int32)
+        d_rp, d_cp = _abi.to_device(step_r, "int32"), _abi.to_device(step_c, "int32")
         lib = _abi.lib()
         before = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).sort().values
         for t in (self._d_samples, self._d_test):
@@ -506,6 +512,9 @@ class ExplicitMF(Recommender):
                                              self.n_users, self.n_items, _abi.ptr(out), _abi.C.byref(cnt),
                                              _abi.stream_ptr()))
         self._d_test = out[:cnt.value].contiguous()
+        # only now that the device arrays are remapped: original id -> current id
+        self.row_perm = step_r if self.row_perm is None else step_r[self.row_perm]
+        self.col_perm = step_c if self.col_perm is None else step_c[self.col_perm]
         if self.samples is not None:
             self.samples = self._d_samples.cpu().numpy()
             self.test_samples = self._d_test.cpu().numpy()

@@ -31,7 +31,6 @@
 #include "common.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
-#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -50,12 +49,11 @@ struct mfsgd_grid {
     int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
     float *val = nullptr;
     int32_t *col_order = nullptr;  // item stripes, heaviest first
-    int32_t *col_hot = nullptr;      // [Gc] the stripe's most rated item (global id) if it is worth a server wave, else -1
+    int32_t *col_hot = nullptr;      // [Gc] the stripe's most rated item (global id) if grouped updates may apply to it, else -1
     int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings of that item in the block
     int32_t *col_hot_deg = nullptr;  // [Gc] ratings of that item in the whole stripe (0 when col_hot < 0)
     int32_t max_block_runs = 0;
     int32_t hot_batch = 1;         // > 1: updates of a stripe's most rated item are applied in groups of this size
-    bool serve_env = false;        // MFSGD_SERVE_HOT at creation: server wave instead (experimental)
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -74,8 +72,7 @@ struct GridView {
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
     const int32_t *col_hot, *blk_hot_cnt, *col_hot_deg;
-    int32_t hot_mode;   // what happens to a stripe's most rated item: 0 nothing special, 1 server wave, 2 grouped updates
-    int32_t hot_shift;  // mode 2: log2 of the group size
+    int32_t hot_shift;  // > 0: grouped updates of a stripe's most rated item, log2 of the group size
 };
 
 struct SchedView {
@@ -84,7 +81,6 @@ struct SchedView {
     uint32_t seed;
     int32_t *err;      // sticky error word: 1 = ticket wait ran out, 2 = row-lock search ran out
     long long *col_clock;
-    int32_t dbg;       // MFSGD_DEBUG_FLAGS (timing experiments only; results are invalid when non-zero)
 };
 
 constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
@@ -96,14 +92,16 @@ constexpr int SPIN_LOCK_SWEEPS = 1 << 20;
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // ------------------------------------------------------------------------------------------ grid build
-__global__ void k_keys(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t ubp, int32_t ibp, int32_t Gr,
-                       int32_t Gc, uint32_t *bkey, uint32_t *ukey, int32_t *idx, int32_t *err)
+__global__ void k_keys(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t ubp, int32_t ibp, int64_t n_users,
+                       int64_t n_items, int32_t Gc, uint32_t *bkey, uint32_t *ukey, int32_t *idx, int32_t *err)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int32_t u = s[t * stride], i = s[t * stride + 1];
     const int32_t r = u / ubp, c = i / ibp;
-    if (u < 0 || i < 0 || r >= Gr || c >= Gc) { *err = 1; bkey[t] = 0; ukey[t] = 0; idx[t] = (int32_t)t; return; }
+    // ids are checked against the factor matrices, not against the padded last stripe: an id in
+    // [n_users, Gr * ubp) would index P / b_u (and the per-item degree table) past their ends
+    if (u < 0 || i < 0 || u >= n_users || i >= n_items) { *err = 1; bkey[t] = 0; ukey[t] = 0; idx[t] = (int32_t)t; return; }
     bkey[t] = (uint32_t)r * (uint32_t)Gc + (uint32_t)c;
     ukey[t] = (uint32_t)u;
     idx[t] = (int32_t)t;
@@ -212,8 +210,8 @@ __global__ void k_item_deg(const int32_t *__restrict__ item, int64_t n, int32_t 
     if (t < n) atomicAdd(&deg[item[t]], 1);
 }
 
-// The most rated item of a stripe gets a server wave (see HotRing) when it carries at least 1/16 of the stripe's
-// ratings, i.e. more than one wave's fair share: below that its chain is not what bounds the stripe.
+// The most rated item of a stripe qualifies for grouped updates (HotItem) when it carries at least 1/16 of the
+// stripe's ratings, i.e. more than one wave's fair share: below that its chain is not what bounds the stripe.
 __global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot,
                           int32_t *col_hot_deg)
 {
@@ -305,41 +303,26 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    uint32_t ctl, tick, rowdone, rowrun, qs, bis, ring_st, ring_s, ring_p, ring_ui, rt_u, rt_t, total;
+    uint32_t ctl, tick, rowdone, rowrun, qs, bis, hot_st, hot_s, hot_p, rt_u, rt_t, total;
 };
 constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
 
-// Server wave of a stripe's most rated item.  SGD on one item's row is a chain: every rating of the item needs
-// the row its predecessor wrote.  Through the LDS ticket that hand-off costs a poll, a row read, the update and
-// a row write per link (~0.3 us), and the most rated items have 10^5 links per epoch.  So the last wave of the
-// workgroup keeps that item's row and bias in REGISTERS for the whole block and serves it: a worker that meets
-// the item posts its user row, bias and rating in ring slot (ticket mod HOT_R) and sleeps; the server takes the
-// slots in ticket order (the next request is prefetched while the current one is computed, so a link costs
-// the arithmetic only), writes the updated user row and bias back into the slot, and the worker picks them up.
-// Slot state word: 3g = free for generation g = ticket / HOT_R, 3g+1 = request posted, 3g+2 = answered.
-// When the item's rating is the LAST of the user's run (most runs have one rating) the worker does not wait:
-// the server itself stores the new user row and bias to HBM and frees the slot, the worker moves on.
-#ifndef MFSGD_HOT_R
-#define MFSGD_HOT_R 16
-#endif
-constexpr int HOT_R = MFSGD_HOT_R;   // slots of the request ring (a power of two)
-template <typename T> struct HotRing {
-    int *st;       // [HOT_R]
-    T *s;          // [HOT_R][2]  {b_u, rating}
-    T *p;          // [HOT_R][k]
-    int *ui;       // [HOT_R][2]  {user, 1 = the worker wants the row back | 0 = last rating of its run: the server stores it}
-    int32_t item;  // global id of the served item, -1: nobody is served in this stripe
-    // Grouped updates (mfsgd_grid_set_hot_batch) reuse the ring's memory, see walk_run.
-    // shift = log2(group size), 0: the ring serves; n_blk = ratings of the item in the current block.
-    int32_t shift, n_blk;
+// Grouped updates of a stripe's most rated item (mfsgd_grid_set_hot_batch): LDS state of the item
+// whose ratings are applied in groups, see walk_run.
+constexpr int HOT_ST_WORDS = 16;   // st[0] newest published version, st[1 + parity] members of the open group done
+template <typename T> struct HotItem {
+    int *st;       // [HOT_ST_WORDS]
+    T *s;          // [2 * group + 4]  s[2] = bias of the odd versions, s[3 + slot] = bias change of a member
+    T *p;          // [2 * group + 1][k]  one row per member of the two open groups, then the odd versions' row
+    int32_t item;  // global id of the stripe's grouped item, -1: none
+    int32_t shift, n_blk;   // log2(group size) (0: no grouping), ratings of the item in the current block
 };
 
 template <typename T>
 LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic, int32_t group = 1)
 {
-    // grouped updates keep one row per member of the two open groups, plus the odd versions' row (walk_run)
-    const size_t ring_rows = std::max<size_t>(HOT_R, group > 1 ? 2 * (size_t)group + 1 : 0);
-    const size_t ring_words = std::max<size_t>(2 * HOT_R, group > 1 ? 2 * (size_t)group + 4 : 0);
+    const size_t hot_rows = group > 1 ? 2 * (size_t)group + 1 : 0;
+    const size_t hot_words = group > 1 ? 2 * (size_t)group + 4 : 0;
     auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsPlan<T> p{};
     size_t o = 0;
@@ -349,10 +332,9 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 12 : 0));
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
-    p.ring_st = o; o = up(o + (stage ? (size_t)HOT_R * 4 : 0));
-    p.ring_s = o; o = up(o + (stage ? ring_words * sizeof(T) : 0));
-    p.ring_p = o; o = up(o + (stage ? ring_rows * k * sizeof(T) : 0));
-    p.ring_ui = o; o = up(o + (stage ? (size_t)HOT_R * 8 : 0));
+    p.hot_st = o; o = up(o + (stage ? (size_t)HOT_ST_WORDS * 4 : 0));
+    p.hot_s = o; o = up(o + (stage ? hot_words * sizeof(T) : 0));
+    p.hot_p = o; o = up(o + (stage ? hot_rows * k * sizeof(T) : 0));
     p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.rt_t = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.total = (uint32_t)std::min<size_t>(o, 0xffffffffu);
@@ -376,7 +358,6 @@ struct RunIdx {
 // Stage 2: the user's row (+ implicit term, bias) and the first 64 ratings of the run, one rating per lane.
 template <typename T, int KC> struct RunHead {
     int32_t u, t0, t1;
-    int32_t real, seq, es;   // streaming kernel: claimed run or hole, block sequence number, queue slot
     T p[KC], zz[KC], bu;
     int32_t m_item, m_tick;
     float m_val;
@@ -454,14 +435,11 @@ __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q
     return e;
 }
 
-// CUM (streaming kernel): tickets count from the start of the column tenure, not of the block; `tbase[il]` is
-// the number of ratings of stripe item il in the blocks of this tenure that precede the run's block.
-template <typename T, int KC, bool STAGE, bool FAST, bool HOT, bool CUM = false>
+template <typename T, int KC, bool STAGE, bool FAST, bool HOT>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
-                                         T *bis, int lane, int32_t *err, const HotRing<T> &hot, const int *tbase,
-                                         int *fl_word, int32_t fl_cnt PF_PARAM)
+                                         T *bis, int lane, int32_t *err, const HotItem<T> &hot PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
     PF_T(w0);
@@ -484,7 +462,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         const int32_t il = ig - c_base;
         int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
-        if (HOT && !CUM && ig == hot.item && hot.shift > 0) {
+        if (HOT && ig == hot.item && hot.shift > 0) {
             // Grouped updates of the stripe's most rated item (opt-in).  The item's ratings tk
             // with the same g = tk >> shift form a group.  Every member of group g reads the item's row and
             // bias in version V_g (V_0 = V_1 = the block's starting values), adds its change to the sums of its
@@ -496,7 +474,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             // Sums are not formed with LDS float atomics (measured: they cost more than the chain they replace):
             // every member stores its change in its own slot and the closer adds the slots up in member order,
             // so the result does not depend on who finished when.
-            // LDS (HotRing memory): st[0] = newest published version, st[1 + par] = members of the open group
+            // LDS (HotItem): st[0] = newest published version, st[1 + par] = members of the open group
             // of that parity that are done; p[(par * B + m) * k ..] / s[3 + par * B + m] = the change member m of
             // that group computed; versions of even groups live in the stripe's own row, those of odd groups in
             // p[2B * k ..] / s[2].
@@ -585,59 +563,12 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             PF_INC(PF_RATINGS, 1);
             continue;
         }
-        if (HOT && FAST && ig == hot.item && hot.shift == 0) {
-            // the stripe's served item: hand the user row to the server wave and take the answer (HotRing)
-            if (CUM) tk += __builtin_amdgcn_readfirstlane(tbase[il]);
-            const int32_t hs = tk & (HOT_R - 1), gen3 = 3 * (tk / HOT_R);
-            int *stw = hot.st + hs;
-            PF_T(h0);
-            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                                    stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != gen3; ++spins) {
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            PF_T(h1);
-            PF_ADD(29, h0, h1);
-#pragma unroll
-            for (int c = 0; c < KC; ++c) hot.p[(size_t)hs * k + lane + 64 * c] = p[c];
-            *sink_ptr(&hot.s[2 * hs], ctl, lane) = bu;
-            *sink_ptr(&hot.s[2 * hs + 1], ctl, lane) = r;
-            const bool handed = !CUM && t == t1 - 1;   // last rating of the run: the server stores row and bias
-            *sink_ptr(&hot.ui[2 * hs], ctl, lane) = u;
-            *sink_ptr(&hot.ui[2 * hs + 1], ctl, lane) = handed ? 0 : 1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS keeps a wave's stores in order
-            __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (handed) {
-                PF_INC(PF_RATINGS, 1);
-                return;
-            }
-            for (int spins = 0;; ++spins) {
-                const int32_t seen = __hip_atomic_load(stw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int c = 0; c < KC; ++c) p[c] = hot.p[(size_t)hs * k + lane + 64 * c];
-                bu = hot.s[2 * hs];
-                if (__builtin_amdgcn_readfirstlane(seen) == gen3 + 2) break;
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __hip_atomic_store(sink_ptr(stw, ctl, lane), gen3 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            PF_T(h2);
-            PF_ADD(30, h1, h2);
-            PF_INC(31, 1);
-            PF_INC(PF_RATINGS, 1);
-            continue;
-        }
         T bi;
         T *qrow = Q + (int64_t)ig * k;
         PF_T(r0);
 #ifdef MFSGD_PROF
         int32_t first_ahead = 0;
 #endif
-        int32_t tb = 0;
-        if (CUM) tb = tbase[il];   // rides in front of the first poll (LDS answers a wave in issue order)
         if (STAGE) {
             // Ticket, Q row and b_i all live in LDS, and the LDS executes one wave's DS instructions in issue
             // order.  So each poll issues the ticket read AND the row reads back to back: if the ticket read
@@ -654,7 +585,6 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                     q[c] = (FAST || f < k) ? qs[(size_t)il * k + f] : (T)0;
                 }
                 bi = bis[il];
-                if (CUM) { tk += __builtin_amdgcn_readfirstlane(tb); tb = 0; }
                 int32_t ahead = tk - __builtin_amdgcn_readfirstlane(seen);
 #ifdef MFSGD_PROF
                 if (spins == 0) { first_ahead = ahead; }
@@ -732,14 +662,6 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         PF_ADD(PF_UPDATE, r1, r2);
     }
     PF_T(w2);
-    if (CUM && fl_cnt > 0) {
-        // Streaming kernel: this is the first run the wave walks in a new block, and the scheduler waits to hear
-        // how many runs of the previous block the wave finished - with their stores complete.  Here, just
-        // before this run's own stores, everything outstanding is at least one walk old: the drain is ~free,
-        // where in front of the walk it would have put a store round trip on the item chains this run is in.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        atomicAdd(sink_ptr(fl_word, ctl, lane), fl_cnt);
-    }
     if (FAST) {
         // Stores the compiler does not see (untracked_store): with a tracked store pending, hipcc's wait
         // insertion treats vmcnt as out of order on gfx9-class targets and turns every later wait for a
@@ -761,79 +683,12 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     PF_ADD(PF_TAIL, w2, w3);
 }
 
-// The server wave's loop (HotRing): `n` requests in ticket order starting at cumulative ticket 0.
-template <typename T, int KC>
-__device__ __forceinline__ void serve_hot(const HotRing<T> &hot, int32_t n, int32_t hl, T *qs, T *bis, int k, int lane,
-                                          int *ctl, T b, T alpha, T beta1, T beta2, int variant, T *__restrict__ P,
-                                          T *__restrict__ b_u, int32_t *err, bool pf_on PF_PARAM)
-{
-    T q[KC], zz[KC], rp[KC], bi, rbu, rr;
-    int32_t seen, ru, rneed;
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) { q[cc] = qs[(size_t)hl * k + lane + 64 * cc]; zz[cc] = 0; }
-    bi = bis[hl];
-    auto fetch = [&](int32_t hs) {   // state word first: LDS serves a wave's reads in order
-        seen = __hip_atomic_load(hot.st + hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int cc = 0; cc < KC; ++cc) rp[cc] = hot.p[(size_t)hs * k + lane + 64 * cc];
-        rbu = hot.s[2 * hs];
-        rr = hot.s[2 * hs + 1];
-        ru = hot.ui[2 * hs];
-        rneed = hot.ui[2 * hs + 1];
-    };
-    __builtin_amdgcn_s_setprio(3);
-    fetch(0);
-    PF_T(sv0);
-    for (int32_t t = 0; t < n; ++t) {
-        const int32_t hs = t & (HOT_R - 1), want = 3 * (t / HOT_R) + 1;
-        PF_T(sv1);
-        for (int spins = 0; __builtin_amdgcn_readfirstlane(seen) != want; ++spins) {
-            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-            if (spins > 4) __builtin_amdgcn_s_sleep(1);
-            fetch(hs);
-            if (pf_on) PF_INC(27, 1);
-        }
-        PF_T(sv2);
-        if (pf_on) { PF_ADD(25, sv1, sv2); PF_INC(26, 1); }
-        T cp[KC], pn[KC];
-#pragma unroll
-        for (int cc = 0; cc < KC; ++cc) cp[cc] = rp[cc];
-        T cbu = rbu;
-        const T rest = rr - b - cbu;
-        const int32_t cu = __builtin_amdgcn_readfirstlane(ru);
-        const bool need = __builtin_amdgcn_readfirstlane(rneed) != 0;
-        fetch((t + 1) & (HOT_R - 1));   // the next request, if it is already there, arrives behind the arithmetic
-        const T e = sgd_step<T, KC, false>(cp, zz, q, bi, rest, alpha, beta1, beta2, variant, pn);
-        cbu += alpha * (e - beta1 * cbu);
-        if (need) {   // the run goes on: hand row and bias back
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) hot.p[(size_t)hs * k + lane + 64 * cc] = pn[cc];
-            *sink_ptr(&hot.s[2 * hs], ctl, lane) = cbu;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {      // the run ends here: store for the worker (drained by this wave before the block's barrier)
-            __hip_atomic_store(sink_ptr(hot.st + hs, ctl, lane), want + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            T *prow = P + (int64_t)cu * k;
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) untracked_store(prow + lane + 64 * cc, pn[cc]);
-            untracked_store(&b_u[cu], cbu);   // all lanes, same word
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    PF_T(sv3);
-    if (pf_on) PF_ADD(24, sv0, sv3);
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) qs[(size_t)hl * k + lane + 64 * cc] = q[cc];
-    *sink_ptr(&bis[hl], ctl, lane) = bi;
-}
-
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
 template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis, int32_t *err, HotRing<T> hot, int *rt_u,
+                                              int *tick_done, T *qs, T *bis, int32_t *err, HotItem<T> hot, int *rt_u,
                                               int *rt_t, int32_t run_lo, int32_t run_hi, int32_t n_hot_blk PF_PARAM)
 {
     constexpr bool HOT = STAGE;
@@ -844,24 +699,16 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
     const bool uniq = FAST || g.user_unique;     // host side: FAST kernels are only launched on user-unique grids
-    int32_t n_hot = 0;
-    if (HOT) {
-        if (hot.shift > 0) {
-            // grouped updates: counters and sums start at zero in every block
-            hot.n_blk = n_hot_blk;
-            if (hot.item >= 0 && n_hot_blk > 0) {
-                const int32_t hl = hot.item - c_base;
-                for (int i = tid; i < k; i += blockDim.x)
-                    hot.p[((size_t)2 << hot.shift) * k + i] = qs[(size_t)hl * k + i];   // V_1 = V_0
-                if (tid == 0) hot.s[2] = bis[hl];
-            }
-        } else {
-            // a server needs workers beside it; a block too long for one run table is walked in chunks with barriers
-            // between them, which a serving wave could not attend
-            if (!FAST || nw < 4 || run_hi - run_lo > RT_CAP) hot.item = -1;
-            if (hot.item >= 0) n_hot = n_hot_blk;
+    if (HOT && hot.shift > 0) {
+        // grouped updates: counters and sums start at zero in every block
+        hot.n_blk = n_hot_blk;
+        if (hot.item >= 0 && n_hot_blk > 0) {
+            const int32_t hl = hot.item - c_base;
+            for (int i = tid; i < k; i += blockDim.x)
+                hot.p[((size_t)2 << hot.shift) * k + i] = qs[(size_t)hl * k + i];   // V_1 = V_0
+            if (tid == 0) hot.s[2] = bis[hl];
         }
-        if (tid < HOT_R) hot.st[tid] = tid == 0 && hot.shift > 0 ? 1 : 0;   // grouped: versions 0 and 1 exist
+        if (tid < HOT_ST_WORDS) hot.st[tid] = tid == 0 ? 1 : 0;   // versions 0 and 1 exist
     }
     if (uniq) {
     for (int32_t lo = run_lo; lo < run_hi; lo += RT_CAP) {   // one trip unless the block has more than RT_CAP runs
@@ -874,12 +721,6 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     }
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
-    if (HOT && FAST && n_hot > 0 && __builtin_amdgcn_readfirstlane(wave) == nw - 1) {
-        // ---- server of the stripe's most rated item (HotRing): row and bias in registers for the whole block
-        serve_hot<T, KC>(hot, n_hot, hot.item - c_base, qs, bis, k, lane, ctl, b, alpha, beta1, beta2, variant, P, b_u, err,
-                         n_hot >= 150 PF_PASS);
-        // nobody reads the item's row before the closing barrier: workers never touch it, later blocks come after
-    }
     {
         // A wave binds itself to TWO runs beyond the one it walks (their head loads are in flight), and claims the
         // next only after the walk.  Claiming further ahead (the index words then came from HBM, two runs early)
@@ -915,7 +756,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         if (JW >= nr) break;                                                                                          \
         load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
         walk_run<T, KC, STAGE, FAST, HOT>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,     \
-                                          tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);           \
+                                          tick_done, qs, bis, lane, err, hot PF_PASS);           \
         JN = claim();                                                                                                 \
         index(JN, x);
         for (;;) {
@@ -945,7 +786,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             run_index(g, j, x);
             load_run<T, KC, false>(g, x, P, b_u, z, k, lane, cur);
             walk_run<T, KC, STAGE, false, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                                 tick_done, qs, bis, lane, err, hot, nullptr, nullptr, 0 PF_PASS);
+                                                 tick_done, qs, bis, lane, err, hot PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -1013,8 +854,8 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
 #endif
-    const bool grouped = STAGE && g.hot_mode == 2;
-    const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p), (int *)(smem + lp.ring_ui),
+    const bool grouped = STAGE && g.hot_shift > 0;
+    const HotItem<T> hot{(int *)(smem + lp.hot_st), (T *)(smem + lp.hot_s), (T *)(smem + lp.hot_p),
                          grouped ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1, grouped ? g.hot_shift : 0, 0};
     process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
                                        bis, s.err, hot, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
@@ -1036,7 +877,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
     unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
-    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, ratings of the served item of block (r, c)
+    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, ratings of the stripe's grouped item in block (r, c)
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
     const int tid = threadIdx.x, lane = tid & 63;
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
@@ -1077,10 +918,9 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
         __syncthreads();
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
-        const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             (int *)(smem + lp.ring_ui),
-                             STAGE && g.hot_mode ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1,
-                             g.hot_mode == 2 ? g.hot_shift : 0, 0};
+        const HotItem<T> hot{(int *)(smem + lp.hot_st), (T *)(smem + lp.hot_s), (T *)(smem + lp.hot_p),
+                             STAGE && g.hot_shift > 0 ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1,
+                             g.hot_shift, 0};
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -1088,7 +928,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                 auto release = [&]() {
                     // every wave drained its stores before the barrier that ended process_block
                     if (held >= 0) {
-                        if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         held = -1;
@@ -1138,7 +978,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                     pos = found + 1 == g.Gr ? 0 : found + 1;
                     ctl[CTL_REMAIN] = remain - 1;
                     // acquire: drop this CU's L1 so that the previous holder's P rows are re-read
-                    if (!(s.dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (s.order_log) {
                         const int32_t slot = __builtin_amdgcn_readlane(
@@ -1155,19 +995,18 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
             if (sched_wave) {
                 // the finished block's row goes back while the other waves already start on the next block
                 if (held >= 0) {
-                    if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 held = r;
             }
             if (r < 0) break;
-            if (!(s.dbg & 4))
-                process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
-                                                  ctl, tick_done, qs, bis, s.err, hot, (int *)(smem + lp.rt_u),
-                                                  (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
-                                                  __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
-                                                  __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]) PF_PASS);
+            process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
+                                              ctl, tick_done, qs, bis, s.err, hot, (int *)(smem + lp.rt_u),
+                                              (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
+                                              __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
+                                              __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]) PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1179,341 +1018,6 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
     unsigned long long *out = (unsigned long long *)(s.col_clock + 2 * g.Gc);
     for (int i = 0; i < PF_SLOTS; ++i)
         atomicAdd((unsigned long long *)sink_ptr(out + i, ctl, lane), pf[i]);
-#endif
-}
-
-// ------------------------------------------------------------------------------ streaming free-block kernel
-// Same schedule, same results as k_epoch_free, without a workgroup barrier per block.  Measured on the
-// netflix shape, k_epoch_free spends ~18 us per block outside the walk (lock search and fences, pipeline fill,
-// closing barrier and the imbalance in front of it) against ~20 us inside it.  Here a workgroup streams
-// through its column:
-//   wave 0 (scheduler) locks user stripes AHEAD of the workers, copies each locked block's run table into LDS,
-//     extends the per-item ticket bases, publishes the block, and releases stripes whose runs are all done;
-//   waves 1.. (workers) claim runs from ONE counter that runs over the whole tenure (run g belongs to the
-//     published block whose cumulative run range holds g), so they never meet at a block boundary;
-//   the last wave serves the stripe's most rated item (HotRing) across blocks, its row in registers for the
-//     whole tenure, when the stripe has such an item.
-// Tickets are cumulative over the tenure: a rating waits for tick_done[item] == base_of_its_block[item] + ticket.
-// A worker tells the scheduler how many runs of a block it finished when it first walks a run of another
-// block or runs out of work, after draining its stores (vmcnt(0)): once per block and wave, nobody else waits.
-constexpr int BQ = 4;         // blocks a workgroup may hold ahead (queue slots)
-enum { CTL_TAIL = 4, CTL_END = 5, CTL_CLAIM = 6 };
-enum { E_ROW = 0, E_NRUNS = 1, E_DONE = 2, E_WORDS = 4 };
-
-struct StreamPlan {  // byte offsets in dynamic LDS (multiples of 16)
-    uint32_t ctl, tick, rowdone, qs, bis, ring_st, ring_s, ring_p, ring_ui, base, ent, cum, rt_u, rt_t, rowrun, total;
-    int32_t trigger; // the next stripe is looked for once this many 256ths of the newest block's runs are claimed
-    int32_t depth;   // user stripes a workgroup may hold at once (1..BQ): rows are scarce when Gr is close to the grid size
-};
-
-template <typename T>
-StreamPlan stream_plan(int32_t ibp, int32_t Gr, int32_t k)
-{
-    auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    StreamPlan p{};
-    size_t o = 0;
-    p.ctl = o; o = up(o + CTL_WORDS * 4);
-    p.tick = o; o = up(o + (size_t)ibp * 4);
-    p.rowdone = o; o = up(o + (size_t)Gr);
-    p.qs = o; o = up(o + (size_t)ibp * k * sizeof(T));
-    p.bis = o; o = up(o + (size_t)ibp * sizeof(T));
-    p.ring_st = o; o = up(o + (size_t)HOT_R * 4);
-    p.ring_s = o; o = up(o + (size_t)HOT_R * 2 * sizeof(T));
-    p.ring_p = o; o = up(o + (size_t)HOT_R * k * sizeof(T));
-    p.ring_ui = o; o = up(o + (size_t)HOT_R * 8);
-    p.base = o; o = up(o + (size_t)BQ * ibp * 4);
-    p.ent = o; o = up(o + (size_t)BQ * E_WORDS * 4);
-    p.cum = o; o = up(o + ((size_t)Gr + 1) * 4);
-    p.rt_u = o; o = up(o + (size_t)BQ * RT_CAP * 4);
-    p.rt_t = o; o = up(o + (size_t)BQ * (RT_CAP + 1) * 4);
-    p.rowrun = o; o = up(o + (size_t)Gr * 8);
-    p.total = (uint32_t)o;
-    return p;
-}
-
-template <typename T, int KC>
-__global__ __launch_bounds__(1024, 8) void k_epoch_stream(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, T alpha, T beta1,
-                                                       T beta2, int variant, int k, StreamPlan lp, SchedView s)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *ctl = (int *)(smem + lp.ctl);
-    int *tick_done = (int *)(smem + lp.tick);
-    unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
-    T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
-    int *base = (int *)(smem + lp.base), *ent = (int *)(smem + lp.ent), *cum = (int *)(smem + lp.cum);
-    int *rt_u = (int *)(smem + lp.rt_u), *rt_t = (int *)(smem + lp.rt_t);
-    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][2] first run and run count of block (r, c)
-    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const T *z = nullptr;
-#ifdef MFSGD_PROF
-    unsigned long long pf[PF_SLOTS] = {};
-#endif
-    for (;;) {
-        if (wave == 0) {
-            const int32_t ci = __builtin_amdgcn_readlane(
-                __hip_atomic_fetch_add(sink_ptr(&s.counters[0], ctl, lane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
-            int32_t col = -1;
-            if (ci < g.n_cols) {
-                col = __builtin_amdgcn_readfirstlane(g.col_order[ci]);
-                s.col_clock[2 * col] = (long long)__builtin_amdgcn_s_memrealtime();
-            }
-            ctl[CTL_COL] = col;
-            ctl[CTL_REMAIN] = 0;
-            ctl[CTL_TAIL] = 0;
-            ctl[CTL_END] = 0;
-            ctl[CTL_CLAIM] = 0;
-        }
-        __syncthreads();
-        const int32_t c = __builtin_amdgcn_readfirstlane(ctl[CTL_COL]);
-        if (c < 0) break;
-        const int32_t c_base = c * g.ibp;
-        int32_t width = (int32_t)(g.n_items - c_base);
-        if (width > g.ibp) width = g.ibp;
-        int32_t mine = 0;
-        for (int r = tid; r < g.Gr; r += blockDim.x) {
-            const int32_t lo = g.blk_run_ptr[r * g.Gc + c], hi = g.blk_run_ptr[r * g.Gc + c + 1];
-            const bool empty = lo == hi;
-            rowrun[2 * r] = lo;
-            rowrun[2 * r + 1] = hi - lo;
-            row_done[r] = empty ? 1 : 0;
-            mine += empty ? 0 : 1;
-        }
-        atomicAdd(&ctl[CTL_REMAIN], mine);
-        for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
-        if (tid < HOT_R) ((int *)(smem + lp.ring_st))[tid] = 0;
-        if (tid < BQ * E_WORDS) ent[tid] = 0;
-        if (tid == 0) cum[0] = 0;
-        stripe_load<T, true>(g, c, Q, b_i, k, qs, bis);
-        __syncthreads();
-        const HotRing<T> hot{(int *)(smem + lp.ring_st), (T *)(smem + lp.ring_s), (T *)(smem + lp.ring_p),
-                             (int *)(smem + lp.ring_ui),
-                             g.hot_mode == 1 ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1, 0, 0};
-        const int32_t hot_total = __builtin_amdgcn_readfirstlane(g.col_hot_deg[c]);
-        if (wave == 0) {
-            // ------------------------------------------------------------------ scheduler
-            int32_t seq = 0, rel = 0, prev_t0 = 0, prev_t1 = 0, ended = 0;
-            int32_t remain = __builtin_amdgcn_readfirstlane(ctl[CTL_REMAIN]);
-            int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
-            for (int idle = 0;;) {
-                bool progressed = false;
-                PF_T(s0);
-                if (rel < seq) {   // oldest held block: all of its runs walked and their stores drained?
-                    const int es = rel & (BQ - 1);
-                    const int32_t done = __builtin_amdgcn_readfirstlane(
-                        __hip_atomic_load(&ent[es * E_WORDS + E_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    const int32_t nr = __builtin_amdgcn_readfirstlane(ent[es * E_WORDS + E_NRUNS]);
-                    if (done == nr) {
-                        const int32_t row = __builtin_amdgcn_readfirstlane(ent[es * E_WORDS + E_ROW]);
-                        if (!(s.dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_store(&s.row_lock[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ++rel;
-                        progressed = true;
-                    }
-                }
-                PF_T(s1);
-                PF_ADD(0, s0, s1);
-                bool want = remain > 0 && seq - rel < lp.depth;
-                if (want && seq > rel) {   // something is queued: take the next stripe only when it will be needed soon
-                    const int32_t claimed = __builtin_amdgcn_readfirstlane(
-                        __hip_atomic_load(&ctl[CTL_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    const int32_t c0 = __builtin_amdgcn_readfirstlane(cum[seq - 1]), c1 = __builtin_amdgcn_readfirstlane(cum[seq]);
-                    want = claimed >= c0 + (((c1 - c0) * lp.trigger) >> 8);
-                }
-                if (want) {   // one sweep over the rows still to do; only rows that look free are tried
-                    int32_t found = -1;
-                    for (int32_t bs = 0; bs < g.Gr && found < 0; bs += 64) {
-                        int32_t r = pos + bs + lane;
-                        while (r >= g.Gr) r -= g.Gr;
-                        bool cand = bs + lane < g.Gr && !row_done[r];
-                        // the peek is an atomic RMW on purpose: it is answered where the CAS is (a load with agent
-                        // scope was seen returning 0 for words whose CAS then failed, a dozen times per block)
-                        int32_t *pw = cand ? &s.row_lock[r] : (int32_t *)(ctl + CTL_SINK + 2 * lane);
-                        const int32_t lockv = __hip_atomic_fetch_or(pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        PF_INC(24, 1);
-                        PF_INC(27, __builtin_popcountll(__ballot(cand)));
-                        cand = cand && lockv == 0;
-                        unsigned long long mask = __ballot(cand);
-                        PF_INC(28, __builtin_popcountll(mask));
-                        // Workgroups that look at the same stretch of rows see the same free ones: each starts at
-                        // its own pseudo-random member of the set, or they would all race for the lowest
-                        int32_t skip = (int32_t)(mix32((uint32_t)(c * 977 + seq) + s.seed) % (uint32_t)(__builtin_popcountll(mask) | 1));
-                        unsigned long long low = 0;
-                        while (skip-- > 0 && (mask & (mask - 1)) != 0) { low |= mask & (0 - mask); mask &= mask - 1; }
-                        while ((mask | low) != 0 && found < 0) {
-                            if (mask == 0) { mask = low; low = 0; }
-                            const int l = __builtin_ctzll(mask);
-                            mask &= mask - 1;
-                            const int32_t rc = __builtin_amdgcn_readlane(r, l);
-                            int32_t expect = 0;
-                            int32_t *w = sink_ptr(&s.row_lock[rc], ctl, lane);
-                            if (lane != 0) expect = 0x7fffffff;   // value select, not control flow
-                            __hip_atomic_compare_exchange_strong(w, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
-                            if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;
-                            PF_INC(26, 1);
-                            PF_INC(25, found < 0 ? 1 : 0);
-                        }
-                    }
-                    PF_T(s2);
-                    PF_ADD(1, s1, s2);
-                    PF_INC(13, found < 0 ? 1 : 0);
-                    if (found >= 0) {
-                        PF_INC(12, 1);
-                        row_done[found] = 1;
-                        pos = found + 1 == g.Gr ? 0 : found + 1;
-                        --remain;
-                        if (s.order_log) {
-                            const int32_t slot = __builtin_amdgcn_readlane(
-                                __hip_atomic_fetch_add(sink_ptr(&s.counters[1], ctl, lane), 1, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT), 0);
-                            s.order_log[2 * (s.log_base + slot)] = found;
-                            s.order_log[2 * (s.log_base + slot) + 1] = c;
-                        }
-                        // the grid arrays are never written: their loads need not wait for the acquire below
-                        const int32_t run_lo = __builtin_amdgcn_readfirstlane(rowrun[2 * found]);
-                        const int32_t nr = __builtin_amdgcn_readfirstlane(rowrun[2 * found + 1]);
-                        const int es = seq & (BQ - 1), ps = (seq - 1) & (BQ - 1);
-                        // run table of the block; entry nr closes the last run
-                        for (int32_t i = lane; i <= nr; i += 64) {
-                            rt_t[es * (RT_CAP + 1) + i] = g.run_start[run_lo + i];
-                            rt_u[es * RT_CAP + (i < nr ? i : 0)] = g.run_user[run_lo + (i < nr ? i : 0)];
-                        }
-                        // ticket bases of this block = bases of the previous one + what the previous one holds
-                        for (int32_t il = lane; il < width; il += 64) base[es * g.ibp + il] = seq ? base[ps * g.ibp + il] : 0;
-                        for (int32_t t = prev_t0 + lane; t < prev_t1; t += 64) {
-                            const int32_t il = g.item[t] - c_base;
-                            atomicMax(&base[es * g.ibp + il], base[ps * g.ibp + il] + g.tick[t] + 1);
-                        }
-                        prev_t0 = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);
-                        prev_t1 = __builtin_amdgcn_readfirstlane(g.run_start[run_lo + nr]);
-                        ent[es * E_WORDS + E_ROW] = found;      // every lane, same value
-                        ent[es * E_WORDS + E_NRUNS] = nr;
-                        ent[es * E_WORDS + E_DONE] = 0;
-                        const int32_t cprev = __builtin_amdgcn_readfirstlane(cum[seq]);
-                        cum[seq + 1] = cprev + nr;
-                        PF_T(s3);
-                        PF_ADD(2, s2, s3);
-                        // acquire: drop this CU's L1 (and stale L2 lines) so the previous holder's rows are re-read
-                        if (!(s.dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        ++seq;
-                        __hip_atomic_store(&ctl[CTL_TAIL], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        progressed = true;
-                        PF_T(s4);
-                        PF_ADD(7, s3, s4);
-                    }
-                }
-                if (remain == 0 && !ended) {
-                    __hip_atomic_store(&ctl[CTL_END], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ended = 1;
-                }
-                if (ended && rel == seq) break;
-                if (progressed) idle = 0;
-                else {
-                    if (++idle >= SPIN_TICKET_MAX) { atomicOr(s.err, 2); break; }
-                    __builtin_amdgcn_s_sleep(4);
-                    PF_INC(8, 1);
-                }
-            }
-        } else if (wave == nw - 1 && hot.item >= 0) {
-            // ------------------------------------------------------------------ server of the most rated item
-            serve_hot<T, KC>(hot, hot_total, hot.item - c_base, qs, bis, k, lane, ctl, b, alpha, beta1, beta2, variant, P,
-                             b_u, s.err, false PF_PASS);
-        } else {
-            // ------------------------------------------------------------------ worker
-            auto claim = [&](bool take) {
-                return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_CLAIM], ctl, lane), take ? 1 : 0), 0);
-            };
-            RunHead<T, KC> cur, h1, h2, nh;
-            cur.real = h1.real = h2.real = 0;
-            cur.u = h1.u = h2.u = 0; cur.t0 = h1.t0 = h2.t0 = 1; cur.t1 = h1.t1 = h2.t1 = 1;
-            cur.seq = h1.seq = h2.seq = -1; cur.es = h1.es = h2.es = 0;
-#pragma unroll
-            for (int cc = 0; cc < KC; ++cc) { cur.p[cc] = h1.p[cc] = h2.p[cc] = 0; cur.zz[cc] = h1.zz[cc] = h2.zz[cc] = 0; }
-            cur.bu = h1.bu = h2.bu = 0; cur.m_item = h1.m_item = h2.m_item = 0; cur.m_tick = h1.m_tick = h2.m_tick = 0;
-            cur.m_val = h1.m_val = h2.m_val = 0;
-            int32_t e = 0;               // lowest block sequence number that can hold this wave's pending claim
-            int32_t gcl = claim(true);   // pending claim: a run number counted over the whole tenure
-            int32_t last_seq = -1, last_es = 0, cnt = 0;
-            auto flush = [&]() {   // tell the scheduler how many runs of block last_seq this wave has finished
-                if (cnt > 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    atomicAdd(sink_ptr(&ent[last_es * E_WORDS + E_DONE], ctl, lane), cnt);
-                    cnt = 0;
-                }
-            };
-            for (int idle = 0;;) {
-                PF_T(w0);
-                PF_INC(22, 1);
-                // END is read before TAIL: once END is seen the TAIL read behind it is final
-                const int32_t endf = __builtin_amdgcn_readfirstlane(
-                    __hip_atomic_load(&ctl[CTL_END], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order; the LDS itself is in order
-                const int32_t tail = __builtin_amdgcn_readfirstlane(
-                    __hip_atomic_load(&ctl[CTL_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                while (e < tail && gcl >= __builtin_amdgcn_readfirstlane(cum[e + 1])) ++e;
-                const bool ok = e < tail;
-                RunIdx x;
-                x.j = 0; x.u = 0; x.t0 = 1; x.t1 = 1;   // a hole: loads go to valid addresses and are never used
-                const int es = e & (BQ - 1);
-                if (ok) {
-                    const int32_t j = gcl - __builtin_amdgcn_readfirstlane(cum[e]);
-                    x.u = rt_u[es * RT_CAP + j];
-                    x.t0 = rt_t[es * (RT_CAP + 1) + j];
-                    x.t1 = rt_t[es * (RT_CAP + 1) + j + 1];
-                }
-                load_run<T, KC, true>(g, x, P, b_u, z, k, lane, nh);
-                nh.real = ok ? 1 : 0; nh.seq = e; nh.es = es;
-                const int32_t nxt_claim = claim(ok);
-                if (ok) gcl = nxt_claim;
-                const bool nothing = !cur.real && !h1.real && !h2.real && !ok;
-                PF_T(w1);
-                PF_ADD(19, w0, w1);
-                if (cur.real) {
-                    int *fl_word = nullptr;
-                    int32_t fl_cnt = 0;
-                    if (cur.seq != last_seq) {   // first run of another block: report the old one from inside the walk
-                        fl_word = &ent[last_es * E_WORDS + E_DONE];
-                        fl_cnt = cnt;
-                        cnt = 0; last_seq = cur.seq; last_es = cur.es;
-                    }
-                    PF_T(w2);
-                    PF_ADD(20, w1, w2);
-                    walk_run<T, KC, true, true, true, true>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant,
-                                                            k, ctl, tick_done, qs, bis, lane, s.err, hot,
-                                                            base + cur.es * g.ibp, fl_word, fl_cnt PF_PASS);
-                    ++cnt;
-                    PF_T(w3);
-                    PF_ADD(21, w2, w3);
-                }
-#ifdef MFSGD_SHALLOW
-                cur = h1; h1 = nh;
-#else
-                cur = h1; h1 = h2; h2 = nh;
-#endif
-                if (nothing) {
-                    PF_INC(23, 1);
-                    flush();
-                    if (endf) break;   // no block will be published any more and the claim lies behind the last one
-                    if (++idle >= SPIN_TICKET_MAX) { atomicOr(s.err, 1); break; }
-                    __builtin_amdgcn_s_sleep(8);
-                } else idle = 0;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        stripe_store<T, true>(g, c, Q, b_i, k, qs, bis);
-        if (wave == 0) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-    }
-#ifdef MFSGD_PROF
-    {
-        unsigned long long *out = (unsigned long long *)(s.col_clock + 2 * g.Gc);
-        for (int i = 0; i < PF_SLOTS; ++i) atomicAdd((unsigned long long *)sink_ptr(out + i, ctl, lane), pf[i]);
-    }
 #endif
 }
 
@@ -1532,7 +1036,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         auto kern = k_epoch_fixed<T, KC, STAGE>;
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
         for (int it = 0; it < iters; ++it) {
-            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8, G->col_clock, 0};
+            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8, G->col_clock};
             for (int d = 0; d <= gv.Gr + gv.Gc - 2; ++d) {
                 const int r0 = std::max(0, d - (gv.Gc - 1)), r1 = std::min(gv.Gr - 1, d);
                 hipLaunchKernelGGL(kern, dim3(r1 - r0 + 1), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z,
@@ -1552,8 +1056,6 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     if constexpr (can8) {
         if (wps8) kern = fast ? k_epoch_free<T, KC, STAGE, true, 8> : k_epoch_free<T, KC, STAGE, false, 8>;
     }
-    const char *dbg_env = getenv("MFSGD_DEBUG_FLAGS");
-    const int32_t dbg = dbg_env ? atoi(dbg_env) : 0;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     if (n_wg <= 0) {
         int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
@@ -1561,32 +1063,10 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         n_wg = prop.multiProcessorCount * per_cu;
     }
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
-    if (STAGE && fast && gv.user_unique && waves >= 4 && G->max_block_runs <= RT_CAP && gv.hot_mode != 2 && getenv("MFSGD_STREAM")) {   // experimental, see DESIGN.md
-        StreamPlan sp = stream_plan<T>(gv.ibp, gv.Gr, k);
-        const char *dep = getenv("MFSGD_STREAM_DEPTH");
-        sp.depth = dep ? atoi(dep) : 2;
-        sp.depth = std::max(1, std::min(sp.depth, (int32_t)BQ));
-        const char *trg = getenv("MFSGD_STREAM_TRIGGER");
-        sp.trigger = trg ? atoi(trg) : 64;
-        if (sp.total <= (size_t)160 * 1024) {
-            auto sk = k_epoch_stream<T, KC>;
-            MF_HIP(hipFuncSetAttribute((const void *)sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.total));
-            for (int it = 0; it < iters; ++it) {
-                MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
-                MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
-                SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it),
-                            G->counters + 8, G->col_clock, dbg};
-                hipLaunchKernelGGL(sk, dim3(n_wg), dim3(threads), sp.total, st, gv, P, Q, b_u, b_i, b, alpha, beta1, beta2,
-                                   variant, k, sp, s);
-                MF_LAUNCH_CHECK();
-            }
-            return MFSGD_OK;
-        }
-    }
     for (int it = 0; it < iters; ++it) {
         MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
         MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
-        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8, G->col_clock, dbg};
+        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8, G->col_clock};
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2,
                            variant, k, lp, s);
         MF_LAUNCH_CHECK();
@@ -1611,7 +1091,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
                 (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->col_hot_deg,
-                G->hot_batch > 1 ? 2 : (G->serve_env ? 1 : 0), 0};
+                0};
     while ((1 << gv.hot_shift) < G->hot_batch) ++gv.hot_shift;
     const bool dynamic = schedule == 1;
     const size_t cap = (size_t)160 * 1024;
@@ -1800,7 +1280,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(ix0.alloc((size_t)n * 4)); MF_HIP(ix1.alloc((size_t)n * 4));
     MF_HIP(err.alloc(4));
     MF_HIP(hipMemsetAsync(err.p, 0, 4, st));
-    hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, ubp, ibp, (int32_t)Gr, (int32_t)Gc,
+    hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, ubp, ibp, n_users, n_items, (int32_t)Gc,
                        bk0.as<uint32_t>(), uk0.as<uint32_t>(), ix0.as<int32_t>(), err.as<int32_t>());
     MF_LAUNCH_CHECK();
     int32_t herr = 0;
@@ -1908,9 +1388,8 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         MF_HIP(hipStreamSynchronize(st));
         G->info.user_unique = hd ? 0 : 1;
     }
-    // 5b. the item of every stripe whose chain gets a server wave, and how often it occurs in each block
-    // Experimental (MFSGD_SERVE_HOT=1): measured slower than the LDS tickets it replaces.
-    G->serve_env = getenv("MFSGD_SERVE_HOT") != nullptr;
+    // 5b. the item of every stripe that grouped updates (mfsgd_grid_set_hot_batch) apply to, and how often it
+    // occurs in each block
     if (G->info.user_unique) {
         DevBuf deg;
         MF_HIP(deg.alloc((size_t)n_items * 4));
@@ -1926,10 +1405,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         std::vector<int32_t> h_hot((size_t)Gc);
         MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
-        for (int32_t v : h_hot) {
-            G->info.n_hot_stripes += v >= 0;
-            G->info.n_served += G->serve_env && v >= 0;
-        }
+        for (int32_t v : h_hot) G->info.n_hot_stripes += v >= 0;
     }
     MF_HIP(hipStreamSynchronize(st));
     // 6. stripe weights (host, Gr*Gc words): heaviest item stripe first

@@ -60,13 +60,25 @@ __global__ void k_remap(int32_t *samples, int64_t n, int32_t stride, const int32
     samples[t * stride + 1] = col_perm[i];
 }
 
-__global__ void k_mark_seen(const int32_t *__restrict__ train, int64_t n, int32_t stride, uint8_t *seen_u,
-                            uint8_t *seen_i)
+__global__ void k_mark_seen(const int32_t *__restrict__ train, int64_t n, int32_t stride, int64_t n_users,
+                            int64_t n_items, uint8_t *seen_u, uint8_t *seen_i, int32_t *err)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    seen_u[train[t * stride]] = 1;  // benign same-value race
-    seen_i[train[t * stride + 1]] = 1;
+    const int32_t u = train[t * stride], i = train[t * stride + 1];
+    if (u < 0 || u >= n_users || i < 0 || i >= n_items) { *err = 1; return; }   // never write outside the tables
+    seen_u[u] = 1;  // benign same-value race
+    seen_i[i] = 1;
+}
+
+// read-only pass in front of k_remap: a bad id must be reported before anything is rewritten in place
+__global__ void k_check_ids(const int32_t *__restrict__ samples, int64_t n, int32_t stride, int64_t n_users,
+                            int64_t n_items, int32_t *err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t u = samples[t * stride], i = samples[t * stride + 1];
+    if (u < 0 || u >= n_users || i < 0 || i >= n_items) *err = 1;
 }
 
 __global__ void k_flag_test(const int32_t *__restrict__ test, int64_t nt, int32_t stride,
@@ -181,13 +193,18 @@ extern "C" int mfsgd_hip_remap(int32_t *samples, int64_t n, int32_t stride, cons
     DevBuf err;
     MF_HIP(err.alloc(4));
     MF_HIP(hipMemsetAsync(err.p, 0, 4, st));
-    hipLaunchKernelGGL(k_remap, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, row_perm, col_perm, n_users,
-                       n_items, err.as<int32_t>());
+    // the remap is in place: ids are validated in a read-only pass first, so a failed call changes nothing
+    hipLaunchKernelGGL(k_check_ids, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, n_users, n_items,
+                       err.as<int32_t>());
     MF_LAUNCH_CHECK();
     int32_t h = 0;
     MF_HIP(hipMemcpyAsync(&h, err.p, 4, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
-    MF_ARG(h == 0, "remap: an id is outside [0,n_users) x [0,n_items)");
+    MF_ARG(h == 0, "remap: an id is outside [0,n_users) x [0,n_items); nothing was rewritten");
+    hipLaunchKernelGGL(k_remap, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, row_perm, col_perm, n_users,
+                       n_items, err.as<int32_t>());
+    MF_LAUNCH_CHECK();
+    MF_HIP(hipStreamSynchronize(st));
     return MFSGD_OK;
 }
 
@@ -199,16 +216,23 @@ extern "C" int mfsgd_hip_filter_test(const int32_t *test, int64_t nt, int32_t st
     *h_count = 0;
     if (nt == 0) return MFSGD_OK;
     hipStream_t st = as_stream(stream);
-    DevBuf su, si, flags, idx, sel, cnt, tmp;
+    MF_ARG(n_users > 0 && n_items > 0, "filter_test: n_users and n_items must be positive");
+    DevBuf su, si, flags, idx, sel, cnt, tmp, err;
     MF_HIP(su.alloc((size_t)n_users)); MF_HIP(si.alloc((size_t)n_items));
+    MF_HIP(err.alloc(4));
+    MF_HIP(hipMemsetAsync(err.p, 0, 4, st));
     MF_HIP(flags.alloc((size_t)nt)); MF_HIP(idx.alloc((size_t)nt * 8)); MF_HIP(sel.alloc((size_t)nt * 8));
     MF_HIP(cnt.alloc(8));
     MF_HIP(hipMemsetAsync(su.p, 0, (size_t)n_users ? (size_t)n_users : 1, st));
     MF_HIP(hipMemsetAsync(si.p, 0, (size_t)n_items ? (size_t)n_items : 1, st));
     if (n) {
-        hipLaunchKernelGGL(k_mark_seen, dim3(nblk(n)), dim3(256), 0, st, train, n, tstride, su.as<uint8_t>(),
-                           si.as<uint8_t>());
+        hipLaunchKernelGGL(k_mark_seen, dim3(nblk(n)), dim3(256), 0, st, train, n, tstride, n_users, n_items,
+                           su.as<uint8_t>(), si.as<uint8_t>(), err.as<int32_t>());
         MF_LAUNCH_CHECK();
+        int32_t h = 0;
+        MF_HIP(hipMemcpyAsync(&h, err.p, 4, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        MF_ARG(h == 0, "filter_test: a train id is outside [0,n_users) x [0,n_items)");
     }
     hipLaunchKernelGGL(k_flag_test, dim3(nblk(nt)), dim3(256), 0, st, test, nt, stride, su.as<uint8_t>(),
                        si.as<uint8_t>(), n_users, n_items, flags.as<uint8_t>(), idx.as<int64_t>());

@@ -1,0 +1,225 @@
+"""`-m gpu` tests of the BASELINE.json configurations at FULL size (synthetic data of workloads.py, the same
+generator and seeds bench.py uses), through the C-ABI.
+
+ * ML-1M shape, k=64: the free-block schedule's logged block order replayed rating by rating on the CPU oracle
+   reproduces the GPU factors (1e-4 relative, north_star's bar for the factors).
+ * ML-25M shape, k=128: north_star's held-out-RMSE gate.  Same data, same id space, same initial factors, same
+   epochs: the deterministic fixed-order run on the reference's (n_threads+1)^2 grid, the free-block schedule with
+   the reference's order inside a block, and the free-block schedule with grouped hot-item updates agree pairwise
+   to 0.002 in held-out RMSE.  One epoch of the free-block run is also replayed on the oracle.
+ * Netflix shape k=128 and Yahoo!Music shape k=256: size-independent properties - every non-empty block issued
+   exactly once per epoch, no bounded wait ran out, block sizes sum to n, the tickets of a sampled block are the
+   ranks of its ratings per item, train and held-out RMSE fall epoch after epoch.
+The numbers these tests print are kept in profiles/r2_rmse_parity.txt."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+HP = (0.006, 0.05, 0.015)
+
+
+def relerr(a, ref):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import recommender_amd
+    from recommender_amd import _abi
+    _abi.require_gpu()
+    return recommender_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _model(ra, name, *, hot_batch=1, deterministic=False, n_threads=15, renumber="balanced", grid=None, k=None,
+           init_seed=1):
+    """ExplicitMF on the named workload: data generated on the GPU, ids renumbered, grid built, factors drawn."""
+    import torch
+    import workloads
+    train, test, U, I, kk = workloads.synth(torch, name)
+    m = ra.ExplicitMF(n_threads=n_threads, n_factors=k or kk, alpha=HP[0], beta1=HP[1], beta2=HP[2], implicit="none",
+                      deterministic=deterministic, hot_batch=hot_batch, grid=grid, verbose=False)
+    m.load_samples_from_device(train, test, U, I)
+    np.random.seed(20240611)
+    if renumber == "balanced":
+        m.balanced_renumber_samples()
+    else:
+        m.random_renumber_samples()          # D2 exactly as the reference (SGDRecommender.py:228-268)
+    g = m.build_grid()
+    m.init_params_device(init_seed)
+    m._to_dev()
+    return m, g
+
+
+def _check_order_log(log, g, blk_run_ptr):
+    """Every non-empty block exactly once per epoch, nothing else."""
+    Gr, Gc = g.info.Gr, g.info.Gc
+    nonempty = np.flatnonzero(np.diff(blk_run_ptr) > 0)
+    for e in range(log.shape[0]):
+        issued = log[e][log[e][:, 0] >= 0]
+        ids = issued[:, 0].astype(np.int64) * Gc + issued[:, 1]
+        assert len(ids) == len(nonempty), (e, len(ids), len(nonempty))
+        assert np.array_equal(np.sort(ids), nonempty), e
+        assert issued[:, 0].max() < Gr and issued[:, 1].max() < Gc
+
+
+def _replay(orc, m, g, log, P, Q, bu, bi, hot_batch=1):
+    """Replay the logged block order on the CPU oracle, in place on the given host factors."""
+    s = m._d_samples.cpu().numpy()
+    Gc, ubp, ibp = g.info.Gc, g.info.ubp, g.info.ibp
+    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
+    order = np.lexsort((s[:, 0], key))          # stable: block, then user, then input order (= order 1 of the grid)
+    ss, ks = s[order], key[order]
+    ptr = np.searchsorted(ks, np.arange(g.info.Gr * Gc + 1))
+    col_hot = g.col_hot() if hot_batch > 1 else np.full(Gc, -1)
+    for e in range(log.shape[0]):
+        for r, c in log[e]:
+            if r < 0:
+                continue
+            orc.sgd(P, Q, bu, bi, m.b, None, ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]], None, None, *HP, implicit=0,
+                    hot_item=int(col_hot[c]), hot_batch=hot_batch)
+
+
+def _host_factors(m):
+    return [m._dev[n].cpu().numpy().copy() for n in ("P", "Q", "b_u", "b_i")]
+
+
+# ------------------------------------------------------------------ config 2: ML-1M shape, k=64
+def test_ml1m_k64_full_size_replays_on_oracle(ra, orc):
+    import torch
+    m, g = _model(ra, "ml1m")
+    assert m.n_factors == 64 and g.info.n > 890_000
+    iters = 2
+    ref = _host_factors(m)
+    log = torch.full((iters * g.info.Gr * g.info.Gc, 2), -1, dtype=torch.int32, device="cuda")
+    m.run_epochs(iters, order_log=log)
+    g.status()
+    log = log.cpu().numpy().reshape(iters, -1, 2)
+    _check_order_log(log, g, g.export()["blk_run_ptr"])
+    _replay(orc, m, g, log, *ref)
+    for name, r_ in zip(("P", "Q", "b_u", "b_i"), ref):
+        assert relerr(m._dev[name].cpu().numpy(), r_.astype(np.float64)) <= 1e-4, name
+
+
+# ------------------------------------------------------------------ config 3: ML-25M shape, k=128 - the RMSE gate
+def test_ml25m_k128_rmse_gate_fixed_vs_free_vs_grouped(ra, orc):
+    """north_star: 'held-out RMSE must match within 0.002'.  The reference's own parallel run is any conflict-free
+    block order with a sequential pass inside each block (RayBlockScheduler.py:148-181, :58)."""
+    import torch
+    epochs = 6
+    runs = {}
+    # same id space (the reference's random shuffle under one seed) and the same initial factors for the three runs
+    for tag, kw in (("fixed", dict(deterministic=True, n_threads=15, renumber="random")),
+                    ("free", dict(hot_batch=1, renumber="random")),
+                    ("grouped", dict(hot_batch=8, renumber="random"))):
+        m, g = _model(ra, "ml25m", **kw)
+        assert m.n_factors == 128
+        if tag == "fixed":
+            assert (g.info.Gr, g.info.Gc, g.info.order) == (16, 16, 0)
+        before = m.device_errors()
+        ref = log = None
+        if tag == "free":
+            ref = _host_factors(m)
+            log = torch.full((g.info.Gr * g.info.Gc, 2), -1, dtype=torch.int32, device="cuda")
+        m.run_epochs(1, order_log=log)
+        if tag == "free":
+            g.status()
+            log = log.cpu().numpy().reshape(1, -1, 2)
+            _check_order_log(log, g, g.export_device()["blk_run_ptr"].cpu().numpy())
+            _replay(orc, m, g, log, *ref)
+            for name, r_ in zip(("P", "Q", "b_u", "b_i"), ref):
+                assert relerr(m._dev[name].cpu().numpy(), r_.astype(np.float64)) <= 1e-4, name
+        m.run_epochs(epochs - 1)
+        runs[tag] = (before, m.device_errors(), (g.info.Gr, g.info.Gc))
+        del m, g
+        torch.cuda.empty_cache()
+    for tag, (b0, b1, gr) in runs.items():
+        print(f"ml25m k=128 {tag:8s} grid {gr[0]}x{gr[1]}: train {b0[0]:.5f} -> {b1[0]:.5f}  held-out {b0[1]:.5f} -> {b1[1]:.5f}")
+    assert runs["fixed"][0] == runs["free"][0] == runs["grouped"][0]          # same start
+    assert runs["fixed"][1][1] < runs["fixed"][0][1] - 0.05                   # it learned
+    for a, b in (("fixed", "free"), ("fixed", "grouped"), ("free", "grouped")):
+        assert abs(runs[a][1][1] - runs[b][1][1]) < 0.002, (a, b, runs[a][1], runs[b][1])
+        assert abs(runs[a][1][0] - runs[b][1][0]) < 0.002, (a, b, runs[a][1], runs[b][1])
+
+
+# ------------------------------------------------------------------ configs 4 and 5: full-size properties
+@pytest.mark.parametrize("name,k,hot_batch", [("netflix", 128, 1), ("netflix", 128, 8), ("yahoo", 256, 1)])
+def test_full_size_properties(ra, name, k, hot_batch):
+    import torch
+    m, g = _model(ra, name, hot_batch=hot_batch)
+    assert m.n_factors == k
+    n = int(m._d_samples.shape[0])
+    assert g.info.n == n and g.info.user_unique == 1
+    d = g.export_device()
+    brp = d["blk_run_ptr"].cpu().numpy()
+    run_start = d["run_start"]
+    assert int(run_start[-1]) == n and int(run_start[0]) == 0
+    blk_ptr = run_start[torch.from_numpy(brp.astype(np.int64)).cuda()].cpu().numpy()     # rating offsets of the blocks
+    sizes = np.diff(blk_ptr)
+    assert sizes.min() >= 0 and sizes.sum() == n and sizes.max() == g.info.max_block
+    # a sampled block (the largest): its ratings lie in the block, users ascend, tickets are per-item ranks
+    bsel = int(np.argmax(sizes))
+    a, b_ = int(blk_ptr[bsel]), int(blk_ptr[bsel + 1])
+    items = d["item"][a:b_].cpu().numpy()
+    ticks = d["tick"][a:b_].cpu().numpy()
+    r_, c_ = divmod(bsel, g.info.Gc)
+    assert items.min() >= c_ * g.info.ibp and items.max() < (c_ + 1) * g.info.ibp
+    ru = d["run_user"][int(brp[bsel]):int(brp[bsel + 1])].cpu().numpy()
+    assert (np.diff(ru) > 0).all() and ru.min() >= r_ * g.info.ubp and ru.max() < (r_ + 1) * g.info.ubp
+    seen = {}
+    for it, tk in zip(items.tolist(), ticks.tolist()):
+        assert tk == seen.get(it, 0)
+        seen[it] = tk + 1
+    del d
+    epochs = 3
+    log = torch.full((epochs * g.info.Gr * g.info.Gc, 2), -1, dtype=torch.int32, device="cuda")
+    errs = [m.device_errors()]
+    for e in range(epochs):
+        m.run_epochs(1, order_log=log[e * g.info.Gr * g.info.Gc:])
+        errs.append(m.device_errors())          # device_errors() checks grid.status() first
+    _check_order_log(log.cpu().numpy().reshape(epochs, -1, 2), g, brp)
+    print(f"{name} k={k} hot_batch={hot_batch} grid {g.info.Gr}x{g.info.Gc}: " +
+          "  ".join(f"{tr:.4f}/{te:.4f}" for tr, te in errs))
+    for (tr0, te0), (tr1, te1) in zip(errs[:-1], errs[1:]):
+        assert tr1 < tr0 and te1 < te0
+    for t in (m._dev["P"], m._dev["Q"], m._dev["b_u"], m._dev["b_i"]):
+        assert bool(torch.isfinite(t).all())
+
+
+def test_grid_rejects_ids_in_the_padding_of_the_last_stripe(ra):
+    """ids in [n_items, Gc*ibp) or [n_users, Gr*ubp) fall inside the grid's last stripes but outside the
+    factor matrices - they must be refused, not followed."""
+    import torch
+    from recommender_amd import _abi
+    from recommender_amd.SGDRecommender import Grid
+    U, I, ubp, ibp = 1000, 1000, 334, 334          # 3 stripes of 334: ids 1000 and 1001 are in the padding
+    ok = torch.tensor([[0, 0, 3], [999, 999, 4]], dtype=torch.int32, device="cuda")
+    Grid(ok, U, I, ubp, ibp, order=1)
+    for bad in ([[0, 1001, 3]], [[1000, 5, 3]], [[0, -1, 3]]):
+        s = torch.cat([ok, torch.tensor(bad, dtype=torch.int32, device="cuda")])
+        with pytest.raises(_abi.MfsgdError, match="outside"):
+            Grid(s, U, I, ubp, ibp, order=1)
+    # the test filter's `seen` tables have n_users / n_items entries: a train id beyond them is refused too
+    out = torch.empty((2, 3), dtype=torch.int32, device="cuda")
+    cnt = _abi.c_i64(0)
+    bad_train = torch.tensor([[0, 1001, 3]], dtype=torch.int32, device="cuda")
+    rc = _abi.lib().mfsgd_hip_filter_test(_abi.ptr(ok), 2, 3, _abi.ptr(bad_train), 1, 3, U, I, _abi.ptr(out),
+                                          _abi.C.byref(cnt), None)
+    assert rc != 0 and b"outside" in _abi.lib().mfsgd_last_error()
+    # remap validates before it writes: a failed call leaves the array as it was
+    s = torch.tensor([[1, 2, 3], [0, 1001, 3]], dtype=torch.int32, device="cuda")
+    perm = torch.arange(1000, dtype=torch.int32, device="cuda").flip(0).contiguous()
+    rc = _abi.lib().mfsgd_hip_remap(_abi.ptr(s), 2, 3, _abi.ptr(perm), _abi.ptr(perm), U, I, None)
+    assert rc != 0 and s.cpu().tolist() == [[1, 2, 3], [0, 1001, 3]]
