@@ -23,7 +23,6 @@ sys.path.insert(0, ROOT)
 from workloads import ALPHA, BASE_SEED, BETA1, BETA2, WORKLOADS, synth, workload_seed  # noqa: E402
 
 HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md
-GROUPED = 8            # group size of the opt-in hot-item mode reported beside the headline
 
 
 def bytes_per_update(k, implicit):
@@ -78,13 +77,13 @@ def cpu_baseline(torch, m, k, implicit):
                       f"{legs['f64']['seconds']:.2f} s (value), fp32 {legs['f32']['seconds']:.2f} s (value_f32)"}
 
 
-def run_leg(args, torch, ra, data, k, hot_batch):
+def run_leg(args, torch, ra, data, k, hot_buffers):
     """One measured configuration: prep (renumber + grid), warm-up epochs, `steps` timed epochs."""
     import numpy as np
     train, test, U, I = data
     m = ra.ExplicitMF(n_threads=15, n_factors=k, alpha=ALPHA, beta1=BETA1, beta2=BETA2, implicit=args.implicit,
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
-                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_batch=hot_batch, verbose=False)
+                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers, verbose=False)
     m.load_samples_from_device(train.clone(), test.clone(), U, I)      # renumbering rewrites the ids in place
     np.random.seed(args.seed % (2 ** 31))
     t0 = time.perf_counter()
@@ -113,7 +112,7 @@ def run_leg(args, torch, ra, data, k, hot_batch):
     grid.status()
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     return {"m": m, "grid": grid, "wall": wall, "kern_ms": kern_ms, "prep_s": prep_s, "rmse0": rmse0,
-            "rmse1": m.device_errors(), "n_train": int(m._d_samples.shape[0]), "hot_batch": hot_batch}
+            "rmse1": m.device_errors(), "n_train": int(m._d_samples.shape[0]), "hot_buffers": hot_buffers}
 
 
 def main():
@@ -130,12 +129,12 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--renumber", default="balanced", choices=["balanced", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-grouped", action="store_true", help="skip the second leg (grouped hot-item updates)")
+    ap.add_argument("--with-tickets-leg", action="store_true",
+                    help="also time the same grid with the hot segments on the ticket path (hot_buffers 0)")
     ap.add_argument("--seed", type=int, default=BASE_SEED)
-    ap.add_argument("--hot-batch", type=int, default=1,
-                    help="1 (default, the headline) = the reference's sequential order inside a block; >1 applies "
-                         "the updates of each stripe's most rated item in groups of this size "
-                         "(mfsgd_grid_set_hot_batch)")
+    ap.add_argument("--hot-buffers", type=int, default=8,
+                    help="LDS row buffers of the hot-item pipeline (mfsgd_grid_set_hot_buffers); 0 = every rating "
+                         "through the item tickets.  Either way a block is walked sequentially in stored order")
     args = ap.parse_args()
 
     import torch
@@ -173,47 +172,43 @@ def main():
     def summarize(leg):
         g = leg["grid"].info
         avg_s = sum(leg["kern_ms"]) / len(leg["kern_ms"]) / 1e3
-        key = f"{args.workload}/k{k}/{args.implicit}/{g.Gr}x{g.Gc}/hb{leg['hot_batch']}"
+        key = f"{args.workload}/k{k}/{args.implicit}/{g.Gr}x{g.Gc}/hot{leg['hot_buffers']}"
         traffic = traffic_db.get(key, {}).get("traffic_bytes")
         achieved = B * leg["n_train"] / avg_s
         return {"value": args.steps * leg["n_train"] / leg["wall"], "ms_per_step": leg["wall"] / args.steps * 1e3,
-                "grid": [g.Gr, g.Gc], "hot_batch": leg["hot_batch"], "avg_kernel_s": avg_s,
+                "grid": [g.Gr, g.Gc], "hot_buffers": leg["hot_buffers"], "avg_kernel_s": avg_s,
                 "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK, "traffic": traffic, "bytes_per_update": B,
                              # what really crosses HBM (the Q stripe lives in LDS): PMC bytes / launch time / peak
                              "traffic_frac": (traffic / avg_s / HBM_PEAK) if traffic else None,
                              "limiter": "VALU issue + LDS ticket hand-offs (DESIGN.md section 4), not HBM bandwidth",
+                             "hot_segment_ratings": int(g.n_hot),
                              "kernel": "k_epoch_free", "kernel_ms": leg["kern_ms"]},
                 "rmse": {"train_before": leg["rmse0"][0], "test_before": leg["rmse0"][1],
                          "train_after": leg["rmse1"][0], "test_after": leg["rmse1"][1]}}
 
-    leg = run_leg(args, torch, ra, (train, test, U, I), k, args.hot_batch)
+    leg = run_leg(args, torch, ra, (train, test, U, I), k, args.hot_buffers)
     head = summarize(leg)
     g = leg["grid"].info
-    order = ("the reference's sequential order inside a block" if args.hot_batch == 1
-             else f"hot-item groups of {args.hot_batch}")
     out = {
         "metric": "rating-updates/sec", "value": head["value"], "unit": "updates/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shape {U}x{I}, {leg['n_train']} train ratings, k={k}, "
                                f"implicit={args.implicit}, grid {g.Gr}x{g.Gc}, {args.renumber} renumbering, "
-                               f"free-block schedule, {order}",
-                   "hot_batch": args.hot_batch, "n_train": leg["n_train"], "k": k, "grid": [g.Gr, g.Gc],
+                               f"free-block schedule, sequential inside a block"
+                               + (" (hot segments on the hot-item pipeline)" if args.hot_buffers else ""),
+                   "hot_buffers": args.hot_buffers, "n_train": leg["n_train"], "k": k, "grid": [g.Gr, g.Gc],
                    "prep_seconds": leg["prep_s"], "max_col_nnz": int(g.max_col_nnz), "max_block": int(g.max_block)},
         "roofline": head["roofline"], "rmse": head["rmse"],
     }
     cpu_m = leg["m"]
-    if args.hot_batch == 1 and not args.no_grouped:
-        # the opt-in relaxation, reported beside the headline and never as `value`
-        leg2 = run_leg(args, torch, ra, (train, test, U, I), k, GROUPED)
+    if args.with_tickets_leg and args.hot_buffers:
+        leg2 = run_leg(args, torch, ra, (train, test, U, I), k, 0)
         s2 = summarize(leg2)
-        out["grouped"] = {"value": s2["value"], "unit": "updates/s", "ms_per_step": s2["ms_per_step"],
-                          "hot_batch": GROUPED, "grid": s2["grid"], "frac": s2["roofline"]["frac"],
-                          "traffic": s2["roofline"]["traffic"], "kernel_ms": s2["roofline"]["kernel_ms"],
-                          "rmse": s2["rmse"],
-                          "note": "updates of each stripe's most rated item applied in groups of 8, one group late "
-                                  "(mfsgd_grid_set_hot_batch): not the reference's order inside a block"}
+        out["tickets_only"] = {"value": s2["value"], "unit": "updates/s", "ms_per_step": s2["ms_per_step"],
+                               "grid": s2["grid"], "frac": s2["roofline"]["frac"], "kernel_ms": s2["roofline"]["kernel_ms"],
+                               "rmse": s2["rmse"]}
         del leg2
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(torch, cpu_m, k, args.implicit)

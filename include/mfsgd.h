@@ -139,14 +139,18 @@ typedef struct mfsgd_grid mfsgd_grid;
 typedef struct {
     int64_t n, n_runs, n_users, n_items;
     int32_t Gr, Gc, ubp, ibp;
-    int32_t order;        /* 0 = reference order inside a block, 1 = user-sorted inside a block */
-    int32_t user_unique;  /* 1 if no user has two runs in one block */
+    int32_t order;        /* 0 = reference order inside a block, 1 = user-sorted inside a block (hot segment first) */
+    int32_t user_unique;  /* 1 if no user has two runs in one segment of a block (always for order 1) */
     int64_t max_block, max_col_nnz, max_row_nnz;
-    int32_t n_hot_stripes; /* item stripes whose most rated item carries >= 1/16 of the stripe's ratings (user_unique grids) */
+    int64_t n_hot;         /* ratings stored in hot segments (order 1; 0 otherwise) */
+    int32_t n_hot_stripes; /* item stripes with a hot item: their most rated item carries >= 1/16 of the stripe's ratings */
+    int32_t reserved;
 } mfsgd_grid_info;
 
 /* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);
- * order 1: rows are additionally sorted by user inside a block (throughput mode: one run per user). */
+ * order 1 (throughput mode): inside a block first the ratings of the stripe's hot item, one run per user (the hot
+ *          segment, see mfsgd_grid_set_hot_buffers), then all other ratings sorted by user (one run per user),
+ *          ties in input order.  If a (user, hot item) pair occurs twice the grid is built without hot segments. */
 int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                       int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info);
@@ -155,23 +159,24 @@ void mfsgd_grid_destroy(mfsgd_grid *g);
  * run_user[n_runs], item[n], val[n], tick[n].  For checking the bucketing bit for bit. */
 int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_start, int32_t *run_user,
                       int32_t *item, float *val, int32_t *tick, void *stream);
-/* Opt-in relaxation of the order INSIDE a block, for the free-block and the fixed schedule alike (group = 1, the
- * default, is the reference's sequential order, numba_methods.py:11-23).  With group = 2,4,..,64 the ratings of
- * each stripe's most rated item (mfsgd_grid_info.n_hot_stripes of them qualify) are taken in groups of `group`
- * in stored order: every member of group g reads the item's row and bias in version V_g, where V_0 = V_1 = the
- * values at the start of the block and V_{g+2} = V_{g+1} + the summed changes of group g - mini-batches of
- * `group` on that one item whose result becomes visible one group late, plain SGD everywhere else.  The reference has no such mode: its own parallel runs (RayBlockScheduler.py:148-181) keep one block
- * sequential and accept any order ACROSS blocks; this mode is judged as north_star judges the throughput path,
- * by RMSE (tests: within 0.002 of the sequential order), and stays checkable update by update against the
- * oracle's restatement of it (orc_sgd_hotbatch).  Why: one item's updates form a serial chain; on Netflix-shaped
- * data the most rated items carry 10^5 ratings each and that chain, not the memory system, bounds their stripes.
- * Needs a grid with user_unique = 1 unless group == 1.  Takes effect from the next epoch call. */
-int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group);
+/* Hot segments (order 1 grids).  One item's updates form a serial chain - every rating needs the item row its
+ * predecessor wrote - and on Netflix-shaped data the most rated items carry 10^5 ratings each, so that chain, not the
+ * memory system, bounds their stripes.  A stripe's most rated item becomes its HOT item when it carries >= 1/16 of
+ * the stripe's ratings (and >= 256); every block of the stripe then stores that item's ratings first, one single-
+ * rating run per user, in user order.  Nothing is relaxed: the block is still walked sequentially in stored order,
+ * and the free-block kernel (fp32, k = 64 or 128, no implicit term) walks a hot segment with the hot-item pipeline - the same
+ * chain of updates, restated so that the serial part of a link is a few scalar operations (Gram tile of the users'
+ * rows on the matrix cores, csrc/epoch.hip phase_a_gram); every other kernel walks it through the item tickets.
+ * The reference has no counterpart (its blocks are walked by one thread, RayBlockScheduler.py:127-143).
+ * mfsgd_grid_set_hot_buffers: how many LDS row buffers (0..8, default 8 = as many as fit; each 32 x (k+4) floats, one per pipeline wave) the pipeline may
+ * take behind the stripe; 0 sends hot segments through the tickets too (same results up to rounding - the tests
+ * replay both on the oracle's plain sequential kernel).  Takes effect from the next epoch call. */
+int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n);
 /* Host-side helper for choosing a grid: bytes of LDS a free-block workgroup needs for item stripes of `ibp`
- * items, `Gr` user stripes, k factors of `elem_size` bytes (4 or 8) and groups of `group` (1 = none); -1 on bad
- * arguments.  A CU has 160 KB: <= 80 KB lets two workgroups share one.  Touches no device.  No counterpart in the
- * reference (its grid is (n_threads+1)^2, SGDRecommender.py:189-192). */
-int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t group);
+ * items, `Gr` user stripes, k factors of `elem_size` bytes (4 or 8) plus `hot_bufs` pipeline row buffers (fp32
+ * only); -1 on bad arguments.  A CU has 160 KB.  Touches no device.  No counterpart in the reference (its grid is
+ * (n_threads+1)^2, SGDRecommender.py:189-192). */
+int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t hot_bufs);
 /* h_col_hot[Gc] (HOST): for every item stripe the global id of the item mfsgd_grid_set_hot_batch applies to,
  * or -1.  Synchronises. */
 int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream);

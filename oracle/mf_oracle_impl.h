@@ -82,89 +82,6 @@ int FN(orc_sgd)(T *P, T *Q, T *b_u, T *b_i, T b, T *y, const T *z,
     return 0;
 }
 
-/* The same pass with ONE item's updates applied in groups, one group late ("hot-item groups").
- * No counterpart in the reference: it restates the library's opt-in relaxation of the
- * within-block order (include/mfsgd.h mfsgd_grid_set_hot_batch), so that the GPU
- * result stays checkable update by update.  Ratings of `hot_item` (global id) are numbered
- * c = 0,1,.. in stored order; group g holds the ratings with c / hot_batch == g (the last group
- * may be short).  Every rating of group g reads the item's row and bias in the version V_g,
- * where V_0 = V_1 = the values at the start of the pass and V_{g+2} = V_{g+1} + (sum of the
- * changes group g computed): a group's changes become visible to the group after the next.
- * The pass leaves V_{last+2} in Q / b_i.  Everything else - every other item, the user side of
- * the hot item's ratings - is exactly orc_sgd.  implicit 0 or 1 only. */
-int FN(orc_sgd_hotbatch)(T *P, T *Q, T *b_u, T *b_i, T b, T *y, const T *z,
-                         const int32_t *samples, int64_t n, int32_t stride,
-                         const int64_t *row_ptrs, const int32_t *col_inds,
-                         int32_t k, int32_t u_off, int32_t i_off,
-                         T alpha, T beta1, T beta2, int32_t variant, int32_t implicit,
-                         int32_t hot_item, int32_t hot_batch)
-{
-    if (implicit == 2 || hot_batch < 1) return -2;
-    int64_t n_hot = 0, c = 0;
-    for (int64_t t = 0; t < n; ++t) n_hot += samples[t * stride + 1] == hot_item;
-    if (n_hot == 0)
-        return FN(orc_sgd)(P, Q, b_u, b_i, b, y, z, samples, n, stride, row_ptrs, col_inds, k, u_off, i_off,
-                           alpha, beta1, beta2, variant, implicit);
-    T *ys = (T *)calloc((size_t)k, sizeof(T));
-    T *acc = (T *)calloc((size_t)k, sizeof(T));
-    T *vcur = (T *)calloc((size_t)k, sizeof(T));    /* V_g of the group being read */
-    T *vnext = (T *)calloc((size_t)k, sizeof(T));   /* V_{g+1} */
-    if (!ys || !acc || !vcur || !vnext) { free(ys); free(acc); free(vcur); free(vnext); return -1; }
-    T *qh = Q + (int64_t)(hot_item - i_off) * k, *bih = b_i + (hot_item - i_off);
-    for (int f = 0; f < k; ++f) vcur[f] = vnext[f] = qh[f];
-    T bcur = *bih, bnext = *bih, accb = 0;
-    int rc = 0;
-    for (int64_t t = 0; t < n && !rc; ++t) {
-        const int32_t ug = samples[t * stride + 0], ig = samples[t * stride + 1];
-        if (ig != hot_item) {
-            rc = FN(orc_sgd)(P, Q, b_u, b_i, b, y, z, samples + t * stride, 1, stride, row_ptrs, col_inds,
-                             k, u_off, i_off, alpha, beta1, beta2, variant, implicit);
-            continue;
-        }
-        const T r = (T)samples[t * stride + 2];
-        T *p = P + (int64_t)(ug - u_off) * k;
-        T *bu = b_u + (ug - u_off);
-        for (int f = 0; f < k; ++f) ys[f] = 0;
-        if (implicit == 1) {
-            if (z) {
-                for (int f = 0; f < k; ++f) ys[f] = z[(int64_t)ug * k + f];
-            } else {
-                const int64_t lo = row_ptrs[ug], hi = row_ptrs[ug + 1];
-                const T R = (T)sqrt((double)(hi - lo)) + (variant == 1 ? (T)1 : (T)0);
-                for (int64_t j = lo; j < hi; ++j) {
-                    const T *yr = y + (int64_t)col_inds[j] * k;
-                    for (int f = 0; f < k; ++f) ys[f] += yr[f];
-                }
-                for (int f = 0; f < k; ++f) ys[f] = (hi > lo || variant == 1) ? ys[f] / R : (T)0;
-            }
-        }
-        T pred = 0;
-        for (int f = 0; f < k; ++f) pred += vcur[f] * (p[f] + ys[f]);
-        pred += *bu + bcur + b;
-        const T e = r - pred;
-        *bu += alpha * (e - beta1 * *bu);
-        accb += alpha * (e - beta1 * bcur);
-        for (int f = 0; f < k; ++f) {
-            const T puf = p[f];
-            p[f] += alpha * (e * vcur[f] - beta2 * puf);
-            acc[f] += alpha * (e * ((variant == 0 ? p[f] : puf) + ys[f]) - beta2 * vcur[f]);
-        }
-        ++c;
-        if (c % hot_batch == 0 || c == n_hot) {          /* the group closes: V_{g+2} = V_{g+1} + its changes */
-            for (int f = 0; f < k; ++f) {
-                const T vnew = vnext[f] + acc[f];
-                vcur[f] = vnext[f]; vnext[f] = vnew; acc[f] = 0;
-            }
-            const T bnew = bnext + accb;
-            bcur = bnext; bnext = bnew; accb = 0;
-        }
-    }
-    for (int f = 0; f < k; ++f) qh[f] = vnext[f];
-    *bih = bnext;
-    free(ys); free(acc); free(vcur); free(vnext);
-    return rc;
-}
-
 /* One half-step of alternating least squares (ALSRecommender.py:118-155, als_step): for every row r of
  * the CSR (users when type == 'user', items - on the transposed CSR - when type == 'item') solve
  *     (F_r^T F_r + lambda * (n_r + 1) * I) x = F_r^T v_r          (ALSRecommender.py:135-139 / :148-152)

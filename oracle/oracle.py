@@ -45,9 +45,8 @@ def _chk(a, dt):
 
 
 def sgd(P, Q, b_u, b_i, b, y, samples, row_ptrs, col_inds, alpha, beta1, beta2,
-        variant=0, implicit=2, idx_offset=(0, 0), z=None, hot_item=-1, hot_batch=1):
-    """In place.  variant 0 = sgd (A1/A2), 1 = sgd2 (A3); implicit 0 none / 1 frozen / 2 full.
-    hot_item >= 0 with hot_batch > 1: that item's updates are applied in groups (orc_sgd_hotbatch)."""
+        variant=0, implicit=2, idx_offset=(0, 0), z=None):
+    """In place.  variant 0 = sgd (A1/A2), 1 = sgd2 (A3); implicit 0 none / 1 frozen / 2 full."""
     suf, ct = _suf(P.dtype)
     for a in (P, Q, b_u, b_i):
         _chk(a, P.dtype)
@@ -56,13 +55,11 @@ def sgd(P, Q, b_u, b_i, b, y, samples, row_ptrs, col_inds, alpha, beta1, beta2,
     ci = None if col_inds is None else np.ascontiguousarray(col_inds, dtype=np.int32)
     if implicit and z is None:
         _chk(y, P.dtype)
-    batched = hot_item >= 0 and hot_batch > 1
-    extra = (C.c_int32(int(hot_item)), C.c_int32(int(hot_batch))) if batched else ()
-    rc = getattr(lib(), ("orc_sgd_hotbatch_" if batched else "orc_sgd_") + suf)(
+    rc = getattr(lib(), "orc_sgd_" + suf)(
         _p(P), _p(Q), _p(b_u), _p(b_i), ct(b), _p(y), _p(z), _p(samples), C.c_int64(samples.shape[0]),
         C.c_int32(samples.shape[1]), _p(rp), _p(ci), C.c_int32(P.shape[1]),
         C.c_int32(idx_offset[0]), C.c_int32(idx_offset[1]), ct(alpha), ct(beta1), ct(beta2),
-        C.c_int32(variant), C.c_int32(implicit), *extra)
+        C.c_int32(variant), C.c_int32(implicit))
     assert rc == 0
     return P, Q, y, b_u, b_i
 

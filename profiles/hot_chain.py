@@ -10,6 +10,7 @@ U = int(sys.argv[1]) if len(sys.argv) > 1 else 140000
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 640
 extra = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # ratings of other items of the stripe, per 100 users
 waves = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+hot_buffers = int(sys.argv[5]) if len(sys.argv) > 5 else None
 rng = np.random.default_rng(3)
 u = np.arange(U)
 s = [np.column_stack([u, np.zeros(U, np.int64), rng.integers(1, 6, U)])]
@@ -20,7 +21,7 @@ if extra:
 a = np.concatenate(s).astype(np.int32)
 a = a[np.unique(a[:, 0].astype(np.int64) * I + a[:, 1], return_index=True)[1]]
 k = 128
-m = ra.ExplicitMF(n_threads=15, n_factors=k, implicit="none", grid=(rows, 1), waves_per_wg=waves, verbose=False)
+m = ra.ExplicitMF(n_threads=15, n_factors=k, implicit="none", grid=(rows, 1), waves_per_wg=waves, hot_buffers=hot_buffers, verbose=False)
 t = torch.from_numpy(a).cuda()
 m.load_samples_from_device(t, t[:10].clone(), U, I)
 g = m.build_grid()
@@ -30,7 +31,7 @@ ts = []
 for _ in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); m.run_epochs(1); g.status(); ts.append(time.perf_counter() - t0)
 dt = min(ts)
-print(f"one stripe: {len(a)} ratings ({U} of the leading item, served={g.info.n_served}), grid {g.info.Gr}x{g.info.Gc}: "
+print(f"one stripe: {len(a)} ratings ({U} of the leading item, {int(g.info.n_hot)} in hot segments, hot_buffers {m.hot_buffers}), grid {g.info.Gr}x{g.info.Gc}: "
       f"{dt*1e3:.2f} ms -> {dt/len(a)*1e6:.3f} us per rating, {len(a)/dt/1e6:.2f} ratings/us")
 if os.environ.get("MFSGD_LIBRARY"):
     import ctypes as C

@@ -7,7 +7,7 @@ Same data, same id space (the reference's random shuffle), same initial factors 
             blocks in row-major order (schedule 0)
   fixedfine the throughput grid (user-sorted blocks), blocks in fixed row-major order (schedule 0)
   free      the throughput grid, on-GPU free-block schedule, sequential inside a block
-  grouped   the same with grouped hot-item updates (hot_batch 8)
+  grouped   the same with the hot segments on the hot-item pipeline (column name kept from round 2a)
 """
 import os
 import sys
@@ -33,7 +33,7 @@ def model(tag):
     if tag == "fixed16":
         m = ra.ExplicitMF(deterministic=True, **kw)
     else:
-        m = ra.ExplicitMF(hot_batch=8 if tag == "grouped" else 1, **kw)
+        m = ra.ExplicitMF(hot_buffers=4 if tag == "grouped" else 0, **kw)
     m.load_samples_from_device(train, test, U, I)
     np.random.seed(20240611)
     m.random_renumber_samples()

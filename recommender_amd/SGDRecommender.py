@@ -71,23 +71,21 @@ def balanced_permutation(deg, width):
     return new_id
 
 
-def lds_bytes(ibp, Gr, k, esz, group=1):
+def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
     """LDS a free-block workgroup needs for item stripes of `ibp` items (lds_plan in csrc/epoch.hip, kept in
-    step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes)."""
+    step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes); `hot_bufs` row buffers of the hot-item
+    pipeline (float32 only, 32 rows of k + 4 floats each) on top."""
     up = lambda x: (x + 15) & ~15
-    rows = 2 * group + 1 if group > 1 else 0
-    words = 2 * group + 4 if group > 1 else 0
     o = up((16 + 128) * 4)
     o = up(o + ibp * 4)
     o = up(o + Gr)
     o = up(o + Gr * 12)
     o = up(o + ibp * k * esz)
     o = up(o + ibp * esz)
-    o = up(o + 16 * 4)
-    o = up(o + words * esz)
-    o = up(o + rows * k * esz)
     o = up(o + 1026 * 4)
     o = up(o + 1026 * 4)
+    if esz == 4:
+        o += min(hot_bufs, 8) * up(32 * (k + 4) * 4)
     return o
 
 
@@ -109,13 +107,13 @@ class Grid:
         """Synchronise and raise if an epoch kernel gave up on a bounded wait."""
         _abi.check(_abi.lib().mfsgd_grid_status(self.handle, _abi.stream_ptr()))
 
-    def set_hot_batch(self, group):
-        """mfsgd_grid_set_hot_batch: apply the updates of each stripe's most rated item in groups of `group`
-        (1 = the reference's sequential order)."""
-        _abi.check(_abi.lib().mfsgd_grid_set_hot_batch(self.handle, int(group)))
+    def set_hot_buffers(self, n):
+        """mfsgd_grid_set_hot_buffers: LDS row buffers (0..4) the hot-item pipeline may use in the free-block kernel;
+        0..8; 0 sends the hot segments through the item tickets like every other rating (same results up to rounding)."""
+        _abi.check(_abi.lib().mfsgd_grid_set_hot_buffers(self.handle, int(n)))
 
     def col_hot(self):
-        """Per item stripe: global id of the item `set_hot_batch` applies to, or -1."""
+        """Per item stripe: global id of the stripe's hot item (its ratings form the blocks' hot segments), or -1."""
         out = np.full(self.info.Gc, -1, dtype=np.int32)
         _abi.check(_abi.lib().mfsgd_grid_col_hot(self.handle, out.ctypes.data_as(_abi.c_vp), _abi.stream_ptr()))
         return out
@@ -164,12 +162,7 @@ class ExplicitMF(Recommender):
                  dtype="float32",        # device arithmetic of the FPSGD path ("float32" | "float64")
                  grid=None,              # (Gr, Gc) of the throughput grid; None = chosen from the shapes
                  exact_errors=True,      # geterrors over all rows (the reference subsamples, mse2)
-                 hot_batch=None,         # None / 1 = the reference's sequential order inside a block (the default).
-                                         # 2..64 (power of two) is an explicit opt-in, throughput mode only: each
-                                         # stripe's most rated item is then updated in groups of this size
-                                         # (include/mfsgd.h mfsgd_grid_set_hot_batch; RMSE within 0.002 of the
-                                         # sequential order, tests/test_gpu_baseline_configs.py).
-                                         # deterministic=True always runs sequentially.
+                 hot_buffers=None,       # LDS row buffers of the hot-item pipeline (None = 8, as many as fit; 0 = ticket path only)
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -184,7 +177,7 @@ class ExplicitMF(Recommender):
         self.dtype = dtype
         self.grid_shape = grid
         self.exact_errors = exact_errors
-        self.hot_batch = 1 if (deterministic or hot_batch is None) else int(hot_batch)
+        self.hot_buffers = 8 if hot_buffers is None else int(hot_buffers)
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -270,16 +263,12 @@ class ExplicitMF(Recommender):
 
     # ------------------------------------------------------------------ the GPU FPSGD path
     def _choose_grid(self):
-        """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table, the rows of
-        the open groups) in LDS, and a CU has 160 KB of it: stripes of <= 80 KB run two 16-wave workgroups per
-        CU (512 at a time), larger ones - and all kernels for k > 128 or float64, which are built for 128 VGPRs -
-        one (256).  With the grouped updates (hot_batch > 1) one workgroup per CU on the 128-VGPR build is also the
-        faster choice for k <= 128 (netflix shape: 32.3 ms against 33.7 ms), so 512 stripes are only chosen for the
-        sequential order, whose item chains are shorter in narrower stripes.  The epoch is a whole number of such rounds, so the stripe
-        count is made 512 or 256 whenever the data allow it - 374 stripes of 86 KB cost ml25m two rounds, the
-        second one a third full (18.4 ms; 256 stripes: 11.1 ms, profiles/).  User stripes: a quarter more than
-        workgroups in flight (row locks are taken at random; measured best on MI355X).  Small inputs shrink both
-        so that a block still holds ~128 ratings (per-block cost - lock, fences, barriers - is microseconds)."""
+        """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table) in LDS, and a CU has
+        160 KB of it.  One 16-wave workgroup per CU on the 128-register build is the default shape: 256 item stripes
+        (one round of the 256 CUs) whenever the stripe plus at least two row buffers of the hot-item pipeline fit, else
+        512 (two stripes per workgroup, handed out heaviest first).  User stripes: an eighth more than workgroups in
+        flight (row locks are taken at random; swept 256..320: flat, 272-288 best).  Small inputs shrink both so that
+        a block still holds ~128 ratings (per-block cost - lock, fences, barriers - is microseconds)."""
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
@@ -287,21 +276,19 @@ class ExplicitMF(Recommender):
             esz = 8 if self.dtype == "float64" else 4
             n = int(self._d_samples.shape[0])
             U, I = self.n_users, self.n_items
-            fits = lambda Gr_, Gc_, cap: lds_bytes(-(-I // Gc_), Gr_, k, esz, self.hot_batch) <= cap
-            two_per_cu = esz == 4 and k <= 128     # wider rows / doubles run with 128 VGPRs: one workgroup per CU
-            if (self.hot_batch == 1 and two_per_cu and U >= 640 and I >= 512 and n >= 150 * 640 * 512
-                    and fits(640, 512, 80 * 1024)):
-                Gr, Gc = 640, 512      # sequential order inside a block: the chains want the narrower stripes
-            elif U >= 288 and I >= 256 and n >= 128 * 288 * 256 and fits(288, 256, 160 * 1024):
-                Gr, Gc = 288, 256      # one workgroup per CU, 128 VGPRs (swept 256..320 rows: flat, 272-288 best)
+            cap = 160 * 1024
+            pipe = esz == 4 and k in (64, 128) and self.hot_buffers > 0     # the kernels the pipeline exists for
+            fits = lambda Gr_, Gc_: lds_bytes(-(-I // Gc_), Gr_, k, esz, min(2, self.hot_buffers) if pipe else 0) <= cap
+            if U >= 288 and I >= 256 and n >= 128 * 288 * 256 and fits(288, 256):
+                Gr, Gc = 288, 256
+            elif U >= 288 and I >= 512 and n >= 128 * 288 * 512 and fits(288, 512):
+                Gr, Gc = 288, 512
             else:
-                ring = (2 * self.hot_batch + 1) * k * esz if self.hot_batch > 1 else 0    # LDS rows of the open groups
-                ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
+                ibp_max = max(1, (120 * 1024) // ((k + 1) * esz + 4))
                 Gc_min = -(-I // ibp_max)
-                # user stripes: a quarter more than workgroups in flight - 512 only if two fit a CU (checked below)
                 Gc = min(I, 512)
                 ibp0 = -(-I // max(Gc, Gc_min))
-                two = two_per_cu and lds_bytes(ibp0, 640, k, esz, self.hot_batch) <= 80 * 1024
+                two = esz == 4 and k <= 128 and lds_bytes(ibp0, 640, k, esz) <= 80 * 1024
                 Gr = min(U, 640 if two else 320)      # Yahoo shape, k=256: 640 -> 320 rows took 276 -> 201 ms
                 want = max(1.0, n / 128.0)
                 if Gr * Gc > want:
@@ -323,8 +310,8 @@ class ExplicitMF(Recommender):
         else:
             ubp, ibp = self._choose_grid()
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1)
-        if self.hot_batch != 1:
-            self._grid.set_hot_batch(self.hot_batch)
+        if self.hot_buffers != 8:
+            self._grid.set_hot_buffers(self.hot_buffers)
         return self._grid
 
     def _to_dev(self):

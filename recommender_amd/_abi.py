@@ -22,7 +22,7 @@ class GridInfo(C.Structure):
                 ("Gr", c_i32), ("Gc", c_i32), ("ubp", c_i32), ("ibp", c_i32),
                 ("order", c_i32), ("user_unique", c_i32),
                 ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64),
-                ("n_hot_stripes", c_i32)]
+                ("n_hot", c_i64), ("n_hot_stripes", c_i32), ("reserved", c_i32)]
 
 
 def _sig_sgd(ct):
@@ -67,7 +67,7 @@ SIGNATURES = {
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mfsgd_lds_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "mfsgd_grid_set_hot_batch": (C.c_int, [c_vp, c_i32]),
+    "mfsgd_grid_set_hot_buffers": (C.c_int, [c_vp, c_i32]),
     "mfsgd_grid_col_hot": (C.c_int, [c_vp, c_vp, c_vp]),
     "mfsgd_grid_status": (C.c_int, [c_vp, c_vp]),
     "mfsgd_grid_col_times": (C.c_int, [c_vp, c_vp, c_vp]),

@@ -44,16 +44,16 @@ struct DevBuf {
 }  // namespace mfprep
 using mfprep::DevBuf;
 
+constexpr int PA_MAX_BUFS_DEFAULT = 8;
 struct mfsgd_grid {
     mfsgd_grid_info info{};
     int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
     float *val = nullptr;
     int32_t *col_order = nullptr;  // item stripes, heaviest first
-    int32_t *col_hot = nullptr;      // [Gc] the stripe's most rated item (global id) if grouped updates may apply to it, else -1
-    int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings of that item in the block
-    int32_t *col_hot_deg = nullptr;  // [Gc] ratings of that item in the whole stripe (0 when col_hot < 0)
+    int32_t *col_hot = nullptr;      // [Gc] the stripe's hot item (global id): its ratings form the hot segment of every block of the stripe; -1: none
+    int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] length of the block's hot segment (ratings of that item, one per user)
     int32_t max_block_runs = 0;
-    int32_t hot_batch = 1;         // > 1: updates of a stripe's most rated item are applied in groups of this size
+    int32_t hot_bufs = PA_MAX_BUFS_DEFAULT;   // LDS row buffers the hot-item pipeline may take (0: ticket path only)
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -71,8 +71,7 @@ struct GridView {
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
-    const int32_t *col_hot, *blk_hot_cnt, *col_hot_deg;
-    int32_t hot_shift;  // > 0: grouped updates of a stripe's most rated item, log2 of the group size
+    const int32_t *col_hot, *blk_hot_cnt;   // [Gc] the stripe's hot item or -1; [Gr*Gc] length of the block's hot segment
 };
 
 struct SchedView {
@@ -125,11 +124,51 @@ __global__ void k_gather_soa(const int32_t *__restrict__ s, int32_t stride, cons
     val[t] = (float)s[o * stride + 2];
 }
 
-__global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user, int64_t n, int32_t *flag)
+// a run = a maximal stretch of one user's ratings inside a block; in the hot segment (hot != nullptr) every rating
+// is a run of its own and the segment's end is a run boundary even if the same user follows
+__global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user,
+                            const uint8_t *__restrict__ hot, int64_t n, int32_t *flag)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    flag[t] = (t == 0 || bkey[t] != bkey[t - 1] || user[t] != user[t - 1]) ? 1 : 0;
+    bool f = t == 0 || bkey[t] != bkey[t - 1] || user[t] != user[t - 1];
+    if (hot && t > 0) f = f || hot[t] || hot[t - 1];
+    flag[t] = f ? 1 : 0;
+}
+
+__global__ void k_item_deg_raw(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t *deg)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(&deg[s[t * stride + 1]], 1);
+}
+
+// order 1 sorts a block's ratings of the stripe's hot item in front of the others: key = 2 * block + (hot ? 0 : 1)
+__global__ void k_hot_block_key(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t Gc,
+                                const int32_t *__restrict__ col_hot, uint32_t *bkey)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t b = bkey[t];
+    bkey[t] = 2 * b + (s[t * stride + 1] == col_hot[b % (uint32_t)Gc] ? 0u : 1u);
+}
+
+__global__ void k_split_hot_key(uint32_t *bkey, int64_t n, uint8_t *hot)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t b = bkey[t];
+    hot[t] = (b & 1u) ? 0 : 1;
+    bkey[t] = b >> 1;
+}
+
+// hot segment: blk_hot_cnt[block] = its length; *dup = 1 if a user occurs twice in one (a duplicate (user, item) pair)
+__global__ void k_hot_count(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user,
+                            const uint8_t *__restrict__ hot, int64_t n, int32_t *blk_hot_cnt, int32_t *dup)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || !hot[t]) return;
+    atomicAdd(&blk_hot_cnt[bkey[t]], 1);
+    if (t > 0 && hot[t - 1] && bkey[t - 1] == bkey[t] && user[t - 1] == user[t]) *dup = 1;
 }
 
 __global__ void k_run_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ excl,
@@ -204,16 +243,12 @@ inline int bits_for(uint64_t maxkey)
     return b;
 }
 
-__global__ void k_item_deg(const int32_t *__restrict__ item, int64_t n, int32_t *deg)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) atomicAdd(&deg[item[t]], 1);
-}
-
-// The most rated item of a stripe qualifies for grouped updates (HotItem) when it carries at least 1/16 of the
-// stripe's ratings, i.e. more than one wave's fair share: below that its chain is not what bounds the stripe.
-__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot,
-                          int32_t *col_hot_deg)
+// The most rated item of a stripe becomes the stripe's HOT item when it carries at least 1/HOT_SHARE_DIV of the
+// stripe's ratings, i.e. more than one wave's fair share: its chain of updates then bounds the stripe, and its
+// ratings are stored as the hot segment in front of every block (hot-item pipeline, phase_a_gram).
+constexpr int HOT_SHARE_DIV = 16;
+constexpr int HOT_MIN_DEG = 256;
+__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t *col_hot)
 {
     const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Gc) return;
@@ -223,18 +258,7 @@ __global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int3
         total += deg[i];
         if (deg[i] > best_deg) { best_deg = deg[i]; best = (int32_t)i; }
     }
-    const bool serve = best_deg >= 256 && (int64_t)best_deg * 16 >= total;
-    col_hot[c] = serve ? best : -1;
-    col_hot_deg[c] = serve ? best_deg : 0;
-}
-
-__global__ void k_blk_hot(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ item, int64_t n, int32_t Gc,
-                          const int32_t *__restrict__ col_hot, int32_t *blk_hot_cnt)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t bid = bkey[t];
-    if (item[t] == col_hot[bid % (uint32_t)Gc]) atomicAdd(&blk_hot_cnt[bid], 1);
+    col_hot[c] = (best_deg >= HOT_MIN_DEG && (int64_t)best_deg * HOT_SHARE_DIV >= total) ? best : -1;
 }
 
 template <typename K, typename V>
@@ -283,7 +307,7 @@ enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_
        PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 32 };
 
 constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
-enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_SINK = 16 };
+enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_TOKEN = 4, CTL_FRONT = 5, CTL_FUSER = 6, CTL_SINK = 16 };
 
 // "Only lane 0 does X" is written WITHOUT a branch everywhere in this file: every lane executes the store or
 // atomic, lane 0 on the real address and lane l>0 on its own sink word in LDS.  Reason (seen in the gfx950
@@ -303,26 +327,19 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    uint32_t ctl, tick, rowdone, rowrun, qs, bis, hot_st, hot_s, hot_p, rt_u, rt_t, total;
+    uint32_t ctl, tick, rowdone, rowrun, qs, bis, rt_u, rt_t, abuf, abuf_bytes, total;
+    int32_t n_abuf;   // row buffers of the hot-item pipeline (phase_a_gram); 0: hot segments go through the tickets
 };
 constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
+constexpr int PA_B = 32;      // ratings per batch of the hot-item pipeline (one 32 x 32 MFMA tile of Gram entries)
+constexpr int PA_MAX_BUFS = PA_MAX_BUFS_DEFAULT;
+constexpr size_t LDS_CAP = (size_t)160 * 1024;
 
-// Grouped updates of a stripe's most rated item (mfsgd_grid_set_hot_batch): LDS state of the item
-// whose ratings are applied in groups, see walk_run.
-constexpr int HOT_ST_WORDS = 16;   // st[0] newest published version, st[1 + parity] members of the open group done
-template <typename T> struct HotItem {
-    int *st;       // [HOT_ST_WORDS]
-    T *s;          // [2 * group + 4]  s[2] = bias of the odd versions, s[3 + slot] = bias change of a member
-    T *p;          // [2 * group + 1][k]  one row per member of the two open groups, then the odd versions' row
-    int32_t item;  // global id of the stripe's grouped item, -1: none
-    int32_t shift, n_blk;   // log2(group size) (0: no grouping), ratings of the item in the current block
-};
-
+// `abufs`: how many row buffers of the hot-item pipeline to place behind the base plan (as many as fit, at most
+// PA_MAX_BUFS); 0 = none wanted.
 template <typename T>
-LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic, int32_t group = 1)
+LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic, int abufs = 0)
 {
-    const size_t hot_rows = group > 1 ? 2 * (size_t)group + 1 : 0;
-    const size_t hot_words = group > 1 ? 2 * (size_t)group + 4 : 0;
     auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
     LdsPlan<T> p{};
     size_t o = 0;
@@ -332,11 +349,14 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 12 : 0));
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
-    p.hot_st = o; o = up(o + (stage ? (size_t)HOT_ST_WORDS * 4 : 0));
-    p.hot_s = o; o = up(o + (stage ? hot_words * sizeof(T) : 0));
-    p.hot_p = o; o = up(o + (stage ? hot_rows * k * sizeof(T) : 0));
     p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
     p.rt_t = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
+    p.abuf = o;
+    p.abuf_bytes = (uint32_t)up((size_t)PA_B * (k + 4) * sizeof(T));
+    p.n_abuf = 0;
+    if (stage && abufs > 0 && o < LDS_CAP)
+        p.n_abuf = (int32_t)std::min<size_t>((size_t)std::min(abufs, PA_MAX_BUFS), (LDS_CAP - o) / p.abuf_bytes);
+    o += (size_t)p.n_abuf * p.abuf_bytes;
     p.total = (uint32_t)std::min<size_t>(o, 0xffffffffu);
     return p;
 }
@@ -435,11 +455,11 @@ __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q
     return e;
 }
 
-template <typename T, int KC, bool STAGE, bool FAST, bool HOT>
+template <typename T, int KC, bool STAGE, bool FAST>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
-                                         T *bis, int lane, int32_t *err, const HotItem<T> &hot PF_PARAM)
+                                         T *bis, int lane, int32_t *err PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
     PF_T(w0);
@@ -462,107 +482,6 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         const int32_t il = ig - c_base;
         int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
         const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
-        if (HOT && ig == hot.item && hot.shift > 0) {
-            // Grouped updates of the stripe's most rated item (opt-in).  The item's ratings tk
-            // with the same g = tk >> shift form a group.  Every member of group g reads the item's row and
-            // bias in version V_g (V_0 = V_1 = the block's starting values), adds its change to the sums of its
-            // group's parity and moves on; whoever finishes a group last forms V_{g+2} = V_{g+1} + sums and
-            // publishes it.  A group's changes thus reach the group after the next: the members of a group sit
-            // in different runs, i.e. on different waves, and with two groups in flight no wave waits for the
-            // item unless it is a whole group ahead of the slowest one - the item's chain of single hand-offs,
-            // which bounds the stripes of the most rated items, is gone.
-            // Sums are not formed with LDS float atomics (measured: they cost more than the chain they replace):
-            // every member stores its change in its own slot and the closer adds the slots up in member order,
-            // so the result does not depend on who finished when.
-            // LDS (HotItem): st[0] = newest published version, st[1 + par] = members of the open group
-            // of that parity that are done; p[(par * B + m) * k ..] / s[3 + par * B + m] = the change member m of
-            // that group computed; versions of even groups live in the stripe's own row, those of odd groups in
-            // p[2B * k ..] / s[2].
-            const int32_t grp = tk >> hot.shift, par = grp & 1, gfirst = grp << hot.shift;
-            int32_t gend = gfirst + (1 << hot.shift);
-            if (gend > hot.n_blk) gend = hot.n_blk;
-            const int32_t gsize = gend - gfirst;
-            const bool last = gend == hot.n_blk;
-            const size_t own = (size_t)il * k, alt = (size_t)((hot.p + ((size_t)2 << hot.shift) * k) - qs);  // one base: DS addressing
-            const size_t mine = par ? alt : own, other = par ? own : alt;
-            T *bmine = par ? &hot.s[2] : &bis[il], *bother = par ? &bis[il] : &hot.s[2];
-            PF_T(g0);
-            T bi;
-            for (int spins = 0;; ++spins) {
-                const int32_t seen = __hip_atomic_load(hot.st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // LDS answers a wave in issue order
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const int f = lane + 64 * c;
-                    q[c] = (FAST || f < k) ? qs[mine + f] : (T)0;
-                }
-                bi = *bmine;
-                if (__builtin_amdgcn_readfirstlane(seen) >= grp) break;
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                __builtin_amdgcn_s_sleep(TICKET_NAP);
-            }
-            PF_T(g1);
-            PF_ADD(29, g0, g1);
-            T part = 0;
-#pragma unroll
-            for (int c = 0; c < KC; ++c) part += q[c] * (FAST ? p[c] : p[c] + zz[c]);
-            const T e = r - b - bu - bi - wave_sum(part);
-            const int32_t gslot = (par << hot.shift);          // first slot of this group
-            T *slotq = hot.p + (size_t)(gslot + (tk - gfirst)) * k;
-#pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const int f = lane + 64 * c;
-                const T pnew = p[c] + alpha * (e * q[c] - beta2 * p[c]);
-                const T pu = variant == 0 ? pnew : p[c];
-                if (FAST || f < k) slotq[f] = alpha * (e * (FAST ? pu : pu + zz[c]) - beta2 * q[c]);
-                p[c] = pnew;
-            }
-            *sink_ptr(&hot.s[3 + gslot + (tk - gfirst)], ctl, lane) = alpha * (e - beta1 * bi);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const int32_t cnt = __builtin_amdgcn_readlane(atomicAdd(sink_ptr(hot.st + 1 + par, ctl, lane), 1), 0) + 1;
-            if (cnt == gsize) {
-                // every member stored its change before it counted itself: the slots are complete.  V_{g+1} is
-                // published by the previous group's closer - nearly always long ago.
-                for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                                        hot.st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < grp + 1; ++spins) {
-                    if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T v[KC], nb = *bother;
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const int f = lane + 64 * c;
-                    v[c] = (FAST || f < k) ? qs[other + f] : (T)0;
-                }
-                T dsum[KC] = {}, dbs = 0;
-                for (int32_t m = 0; m < gsize; ++m) {
-#pragma unroll
-                    for (int c = 0; c < KC; ++c) {
-                        const int f = lane + 64 * c;
-                        if (FAST || f < k) dsum[c] += hot.p[(size_t)(gslot + m) * k + f];
-                    }
-                    dbs += hot.s[3 + gslot + m];
-                }
-                // V_{g+2} replaces V_g (all its readers are done); the block's last group leaves it in the stripe
-                const size_t dst = last ? own : mine;
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const int f = lane + 64 * c;
-                    if (FAST || f < k) qs[dst + f] = v[c] + dsum[c];
-                }
-                *sink_ptr(last ? &bis[il] : bmine, ctl, lane) = nb + dbs;
-                *sink_ptr(hot.st + 1 + par, ctl, lane) = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __hip_atomic_store(sink_ptr(hot.st, ctl, lane), grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            PF_T(g2);
-            PF_ADD(30, g1, g2);
-            PF_INC(31, 1);
-            bu += alpha * (e - beta1 * bu);
-            PF_INC(PF_RATINGS, 1);
-            continue;
-        }
         T bi;
         T *qrow = Q + (int64_t)ig * k;
         PF_T(r0);
@@ -683,15 +602,219 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     PF_ADD(PF_TAIL, w2, w3);
 }
 
+// ------------------------------------------------------------------------------------ the hot-item pipeline
+// A stripe's most rated item (col_hot) has its ratings FIRST in every block of the stripe, one rating per user, in
+// user order (the "hot segment", see mfsgd_grid_create).  Its updates form a chain - every rating needs the item row
+// its predecessor wrote - and on Netflix-shaped data the longest such chain, 140 K links of ~0.25 us through the LDS
+// tickets, sets the epoch time.  This pipeline walks the SAME chain in the SAME order with the same arithmetic per
+// link, but restated so that the serial part of a link is a handful of scalar operations:
+//   with a = 1 - alpha*beta2, one update (numba_methods.py:17-22) is
+//       e   = r - b - b_u - b_i - q.p          p' = a p + alpha e q
+//       q'  = a q + alpha e p'  =  c q + d p   with c = a + alpha^2 e^2, d = alpha a e      (sgd2 order: c = a, d = alpha e)
+//   so inside a batch of 32 consecutive ratings the item row stays in span{q_0, p_1 .. p_32}, and the dot products
+//   the chain needs follow from the batch's Gram matrix G = P_b P_b^T (one 32x32 MFMA tile, k/2 v_mfma_f32_32x32x2
+//   - computed BEFORE the wave's turn, off the chain) and g = P_b q_0 (when the turn comes):
+//       s_j = q_cur . p_j  starts as g_j and becomes  c_i s_j + d_i G_ij  after link i      (one FMA pair per lane)
+//   Link i itself is: read s_i and (r - b - b_u)_i from lane i, e_i, b_i, c_i, d_i - no LDS, no poll, no wave
+//   reduction.  The batch's final row  q_32 = gamma q_0 + sum_i W_i p_i  is written back to the stripe and the turn
+//   passes to the wave that holds the next batch; the user rows p_j' (which need every intermediate q_j) are then
+//   formed off the chain by running q forward once more with the now known e_j.
+// In exact arithmetic this IS the sequential pass; in fp32 it differs from it by rounding only (the tests replay
+// the block order on the CPU restatement of the plain sequential kernel: factors to 1e-4, as for every other item).
+// Waves 0 .. n_abuf-1 take batches round robin; each owns one LDS row buffer of PA_B x (k + 4) floats.  The other
+// waves walk the rest of the block meanwhile: a rest run may load its user's row once the pipeline has published
+// that the segment is done up to that user (CTL_FUSER; both are in user order), so the two never touch one row.
+typedef float pa_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pa_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KC>
+__device__ __forceinline__ void phase_a_gram(const int32_t *__restrict__ hu, const float *__restrict__ hv, int32_t nh,
+                                             float *__restrict__ P,
+                                             float *__restrict__ b_u, float b, float alpha, float beta1, float beta2,
+                                             int variant, float *qrow, float *bip, float *abuf, uint32_t abuf_floats,
+                                             int n_abuf, int *ctl, int32_t *err PF_PARAM)
+{
+    constexpr int K = 64 * KC, LD = K + 4;
+    constexpr int LPR = K / 4, RPI = 64 / LPR;     // lanes per row and rows per 128-bit load instruction
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= n_abuf) return;
+    float *buf = abuf + (size_t)wave * abuf_floats;
+    const int col = lane & 31, kh = lane >> 5;
+    const int32_t nbatch = (nh + PA_B - 1) / PA_B;
+    const float a = 1.f - alpha * beta2;
+    for (int32_t m = wave; m < nbatch; m += n_abuf) {
+        const int32_t base = m * PA_B;
+        const int32_t nb = nh - base < PA_B ? nh - base : PA_B;
+        // entry j of the batch lives in lanes j and j + 32 (entries past nb repeat the last one and are never applied)
+        const int32_t ej = col < nb ? col : nb - 1;
+        const int32_t uj = hu[base + ej];           // the segment's users and ratings come straight from the grid arrays
+        const float buj = __hip_atomic_load(&b_u[uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const float rest = hv[base + ej] - b - buj;
+        PF_T(a0);
+        // 1. the users' rows -> LDS, natural layout, with coalesced 128-bit loads (RPI whole rows per instruction)
+        {
+            const int rsub = lane / LPR, cpos = (lane % LPR) * 4;
+#pragma unroll 8
+            for (int t = 0; t < PA_B / RPI; ++t) {
+                const int row = t * RPI + rsub;
+                const int32_t ur = __builtin_amdgcn_ds_bpermute(4 * row, uj);   // lane `row` holds entry `row`
+                const pa_f32x4 v = *(const pa_f32x4 *)(P + (int64_t)ur * K + cpos);
+                *(pa_f32x4 *)(buf + row * LD + cpos) = v;
+            }
+        }
+        PF_PIN(buf[lane]);
+        PF_T(a1);
+        PF_ADD(20, a0, a1);
+        // 2. Gram tile: lane (col, kh) feeds P_b[col][8t + 4kh + c] as BOTH operands of MFMA 4t + c
+        pa_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float *rp = buf + col * LD + 4 * kh;
+#pragma unroll 4
+        for (int t = 0; t < K / 8; ++t) {
+            const pa_f32x4 v = *(const pa_f32x4 *)(rp + 8 * t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
+        }
+        // 3. lane (j, 0) gets the whole column j: acc[4a + b] is row 8a + b there and row 8a + 4 + b in lane (j, 1).
+        //    Only the lower half's G (and s below) is meaningful; the upper half computes along and is never read.
+        float G[PA_B];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);
+            G[8 * (v / 4) + (v % 4)] = acc[v];
+            G[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(kh ? sw[0] : sw[1]);
+        }
+        PF_PIN(G[0]); PF_PIN(G[31]);
+        PF_T(a2);
+        PF_ADD(21, a1, a2);
+        // 4. the wave's turn
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN], __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order; the LDS serves a wave in issue order
+        __builtin_amdgcn_s_setprio(2);
+        PF_T(a3);
+        PF_ADD(22, a2, a3);
+        // 5. g_j = q_0 . p_j: each half of the wave sums its chunks, the halves are added
+        float q0[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) q0[c] = qrow[lane + 64 * c];
+        float bi = *bip;
+        float s;
+        {
+            float part = 0;
+#pragma unroll 4
+            for (int t = 0; t < K / 8; ++t) {
+                const pa_f32x4 pv = *(const pa_f32x4 *)(rp + 8 * t);
+                const pa_f32x4 qv = *(const pa_f32x4 *)(qrow + 8 * t + 4 * kh);
+                part += pv.x * qv.x; part += pv.y * qv.y; part += pv.z * qv.z; part += pv.w * qv.w;
+            }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+            s = part + __uint_as_float(kh ? sw[0] : sw[1]);
+        }
+        PF_PIN(s);
+        PF_T(a4);
+        PF_ADD(23, a3, a4);
+        // 6. the chain
+        float evec = 0, wvec = 0, gam = 1;
+#pragma unroll
+        for (int i = 0; i < PA_B; ++i) {
+            if (i < nb) {   // wave-uniform
+                const float si = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), i));
+                const float ri = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rest), i));
+                const float e = ri - bi - si;
+                bi += alpha * (e - beta1 * bi);
+                const float c = variant == 0 ? a + (alpha * alpha) * (e * e) : a;
+                const float d = variant == 0 ? (alpha * a) * e : alpha * e;
+                s = c * s + d * G[i];
+                wvec = col == i ? d : c * wvec;
+                evec = col == i ? e : evec;
+                gam *= c;
+            }
+        }
+        PF_PIN(s); PF_PIN(wvec);
+        PF_T(a5);
+        PF_ADD(24, a4, a5);
+        // 7. q_nb = gamma q_0 + sum_i W_i p_i, back into the stripe; the turn passes on
+        {
+            float qn[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) qn[c] = gam * q0[c];
+            // entries past nb have W = 0 (wvec starts at 0 and is only scaled): the loop runs over the whole batch,
+            // unrolled, so that the LDS reads are in flight together
+#pragma unroll 8
+            for (int32_t i = 0; i < PA_B; ++i) {
+                const float wi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wvec), i));
+#pragma unroll
+                for (int c = 0; c < KC; ++c) qn[c] += wi * buf[i * LD + lane + 64 * c];
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) qrow[lane + 64 * c] = qn[c];
+            *sink_ptr(bip, ctl, lane) = bi;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PF_T(a6);
+        PF_ADD(25, a5, a6);
+        // 8. off the chain: the users' new rows and biases (q runs forward once more, now with every e_j known)
+        {
+            float q[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) q[c] = q0[c];
+#pragma unroll 2
+            for (int32_t j = 0; j < nb; ++j) {
+                const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(evec), j));
+                const int32_t u = __builtin_amdgcn_readlane(uj, j);
+                float *prow = P + (int64_t)u * K;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const float pj = buf[j * LD + lane + 64 * c];
+                    const float pn = pj + alpha * (e * q[c] - beta2 * pj);
+                    const float pu = variant == 0 ? pn : pj;
+                    q[c] = q[c] + alpha * (e * pu - beta2 * q[c]);
+                    untracked_store(prow + lane + 64 * c, pn);
+                }
+            }
+            if (lane < nb) untracked_store(&b_u[uj], buj + alpha * (evec - beta1 * buj));
+        }
+        // The batch's users are done once these stores are: publish it.  Batches are published in order (the frontier
+        // is "every user of the segment up to this one"), so a wave may have to let an earlier batch go first.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_FRONT], __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        {
+            const int32_t last_user = m + 1 == nbatch ? 0x7fffffff : __builtin_amdgcn_readlane(uj, PA_B - 1);
+            __hip_atomic_store(sink_ptr(&ctl[CTL_FUSER], ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __hip_atomic_store(sink_ptr(&ctl[CTL_FRONT], ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        PF_T(a7);
+        PF_ADD(26, a6, a7);
+        PF_INC(27, 1);
+    }
+}
+
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
-template <typename T, int KC, bool STAGE, bool FAST>
+// Runs [run_lo, run_lo + n_hot_blk) are the block's hot segment (one single-rating run per user who rated the
+// stripe's most rated item, see mfsgd_grid_create); the same users' other ratings follow in the rest of the block,
+// so the segment is finished - stores drained, barrier - before the rest starts.  FASTA: the segment goes through
+// the hot-item pipeline (phase_a_gram) when the launch gave it LDS row buffers; otherwise it is walked like any other
+// run, through the item's tickets.
+template <typename T, int KC, bool STAGE, bool FAST, bool FASTA>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
-                                              int *tick_done, T *qs, T *bis, int32_t *err, HotItem<T> hot, int *rt_u,
-                                              int *rt_t, int32_t run_lo, int32_t run_hi, int32_t n_hot_blk PF_PARAM)
+                                              int *tick_done, T *qs, T *bis, int32_t *err, int *rt_u, int *rt_t,
+                                              int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, int32_t hot_item,
+                                              char *abuf, uint32_t abuf_bytes, int n_abuf PF_PARAM)
 {
-    constexpr bool HOT = STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
     const int32_t c_base = c * g.ibp;
@@ -699,20 +822,23 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
     const bool uniq = FAST || g.user_unique;     // host side: FAST kernels are only launched on user-unique grids
-    if (HOT && hot.shift > 0) {
-        // grouped updates: counters and sums start at zero in every block
-        hot.n_blk = n_hot_blk;
-        if (hot.item >= 0 && n_hot_blk > 0) {
-            const int32_t hl = hot.item - c_base;
-            for (int i = tid; i < k; i += blockDim.x)
-                hot.p[((size_t)2 << hot.shift) * k + i] = qs[(size_t)hl * k + i];   // V_1 = V_0
-            if (tid == 0) hot.s[2] = bis[hl];
+    int32_t seg_lo = run_lo, seg_hi = n_hot_blk > 0 ? run_lo + n_hot_blk : run_hi;
+    bool gated = false;   // the pipeline walks the hot segment WHILE the other waves walk the rest behind its frontier
+    if constexpr (FASTA) {
+        if (n_abuf > 0 && n_hot_blk > 0) {
+            gated = true;
+            // every thread, same values; made visible by the barrier behind the first run table below
+            ctl[CTL_TOKEN] = 0;
+            ctl[CTL_FRONT] = 0;
+            ctl[CTL_FUSER] = g.run_user[run_lo] - 1;   // users below the segment's first one have no rating in it
+            seg_lo = seg_hi; seg_hi = run_hi;
         }
-        if (tid < HOT_ST_WORDS) hot.st[tid] = tid == 0 ? 1 : 0;   // versions 0 and 1 exist
     }
     if (uniq) {
-    for (int32_t lo = run_lo; lo < run_hi; lo += RT_CAP) {   // one trip unless the block has more than RT_CAP runs
-    const int32_t nr = run_hi - lo < RT_CAP ? run_hi - lo : RT_CAP;
+    for (;;) {   // the hot segment (unless the pipeline took it), then the rest
+    // one trip unless the segment has more than RT_CAP runs (and one trip for an empty rest behind a pipelined segment)
+    for (int32_t lo = seg_lo; lo < seg_hi || (gated && lo == seg_lo); lo += RT_CAP) {
+    const int32_t nr = seg_hi - lo < RT_CAP ? seg_hi - lo : RT_CAP;
     // the chunk's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
     for (int i = tid; i <= nr + 1; i += blockDim.x) {
         const int ii = i < nr ? i : nr;
@@ -721,6 +847,15 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     }
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
+    if constexpr (FASTA) {
+        if (gated && lo == run_lo + n_hot_blk) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segment first
+            const int32_t t_lo = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);   // single-rating runs: rating = t_lo + i
+            phase_a_gram<KC>(g.run_user + run_lo, g.val + t_lo, n_hot_blk, (float *)P, (float *)b_u, (float)b, (float)alpha,
+                             (float)beta1, (float)beta2, variant, (float *)qs + (size_t)(hot_item - c_base) * k,
+                             (float *)bis + (hot_item - c_base), (float *)abuf, abuf_bytes / 4, n_abuf < nw ? n_abuf : nw,
+                             ctl, err PF_PASS);
+        }
+    }
     {
         // A wave binds itself to TWO runs beyond the one it walks (their head loads are in flight), and claims the
         // next only after the walk.  Claiming further ahead (the index words then came from HBM, two runs early)
@@ -734,6 +869,17 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         auto index = [&](int32_t jj, RunIdx &x) {
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
+            if constexpr (FASTA) {
+                if (gated && jj < nr) {   // the user's row may be loaded once the hot segment is done up to this user
+                    const int32_t u = __builtin_amdgcn_readfirstlane(x.u);
+                    for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                                            &ctl[CTL_FUSER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < u; ++spins) {
+                        if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
         };
         // The run loop is unrolled three times and the three heads change roles instead of being copied
         // (cur = nxt; nxt = far cost ~16 v_mov per run): the kernel is bound by VALU issue,
@@ -755,8 +901,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
 #define MF_STEP(WALK, LOAD, JW, JN)                                                                                     \
         if (JW >= nr) break;                                                                                          \
         load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
-        walk_run<T, KC, STAGE, FAST, HOT>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,     \
-                                          tick_done, qs, bis, lane, err, hot PF_PASS);           \
+        walk_run<T, KC, STAGE, FAST>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,          \
+                                     tick_done, qs, bis, lane, err PF_PASS);                                          \
         JN = claim();                                                                                                 \
         index(JN, x);
         for (;;) {
@@ -768,11 +914,14 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         }
 #undef MF_STEP
     }
-    if (lo + RT_CAP < run_hi) {   // another chunk follows: its table replaces this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lo + RT_CAP < seg_hi || seg_hi != run_hi) {   // another chunk or the rest of the block follows: new table,
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // and the segment's user rows are stored before the same users' runs load them
         __syncthreads();
     }
     }   // chunks
+    if (seg_hi == run_hi) break;
+    seg_lo = seg_hi; seg_hi = run_hi;
+    }   // segments
     }   // uniq
     if (!FAST) {
     if (!uniq) {
@@ -785,8 +934,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             RunIdx x;
             run_index(g, j, x);
             load_run<T, KC, false>(g, x, P, b_u, z, k, lane, cur);
-            walk_run<T, KC, STAGE, false, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
-                                                 tick_done, qs, bis, lane, err, hot PF_PASS);
+            walk_run<T, KC, STAGE, false>(g, cur, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,
+                                          tick_done, qs, bis, lane, err PF_PASS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the user's next run reloads this P row
         }
     }
@@ -854,14 +1003,12 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
 #endif
-    const bool grouped = STAGE && g.hot_shift > 0;
-    const HotItem<T> hot{(int *)(smem + lp.hot_st), (T *)(smem + lp.hot_s), (T *)(smem + lp.hot_p),
-                         grouped ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1, grouped ? g.hot_shift : 0, 0};
-    process_block<T, KC, STAGE, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done, qs,
-                                       bis, s.err, hot, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
-                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
-                                       __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]),
-                                       grouped ? __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[r * g.Gc + c]) : 0 PF_PASS);
+    const int32_t n_hot_blk = __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[r * g.Gc + c]);
+    process_block<T, KC, STAGE, false, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
+                                              qs, bis, s.err, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
+                                              __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
+                                              __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), n_hot_blk,
+                                              -1, nullptr, 0, 0 PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -873,11 +1020,13 @@ template <typename T, int KC, bool STAGE, bool FAST, int WPS>
 __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
+    // the hot-item pipeline needs fp32 MFMA, 128 registers and row buffers in LDS (lp.n_abuf > 0)
+    constexpr bool FASTA = FAST && STAGE && sizeof(T) == 4 && KC <= 2 && WPS == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
     unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
-    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, ratings of the stripe's grouped item in block (r, c)
+    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, length of the block's hot segment (r, c)
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
     const int tid = threadIdx.x, lane = tid & 63;
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
@@ -918,9 +1067,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
         __syncthreads();
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
-        const HotItem<T> hot{(int *)(smem + lp.hot_st), (T *)(smem + lp.hot_s), (T *)(smem + lp.hot_p),
-                             STAGE && g.hot_shift > 0 ? __builtin_amdgcn_readfirstlane(g.col_hot[c]) : -1,
-                             g.hot_shift, 0};
+        const int32_t hot_item = __builtin_amdgcn_readfirstlane(g.col_hot[c]);
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -1002,11 +1149,12 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                 held = r;
             }
             if (r < 0) break;
-            process_block<T, KC, STAGE, FAST>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
-                                              ctl, tick_done, qs, bis, s.err, hot, (int *)(smem + lp.rt_u),
-                                              (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
-                                              __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
-                                              __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]) PF_PASS);
+            process_block<T, KC, STAGE, FAST, FASTA>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
+                                                     ctl, tick_done, qs, bis, s.err, (int *)(smem + lp.rt_u),
+                                                     (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
+                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
+                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]), hot_item,
+                                                     smem + lp.abuf, lp.abuf_bytes, lp.n_abuf PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1027,7 +1175,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
                   int32_t *order_log, hipStream_t st)
 {
     const bool dynamic = schedule == 1;
-    const LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_batch);
+    LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic);
     if (waves <= 0) waves = 16;
     if (waves > 16) waves = 16;
     const int threads = waves * 64;
@@ -1056,6 +1204,10 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     if constexpr (can8) {
         if (wps8) kern = fast ? k_epoch_free<T, KC, STAGE, true, 8> : k_epoch_free<T, KC, STAGE, false, 8>;
     }
+    // the hot-item pipeline (phase_a_gram): fp32, k = 64 or 128, the 128-register build, and as many row buffers as
+    // the LDS left by the stripe holds (at most G->hot_bufs); without a buffer the hot segments take the ticket path
+    if (!wps8 && fast && STAGE && sizeof(T) == 4 && KC <= 2 && G->info.n_hot > 0 && G->hot_bufs > 0)
+        lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs);
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     if (n_wg <= 0) {
         int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
@@ -1090,17 +1242,10 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->col_hot_deg,
-                0};
-    while ((1 << gv.hot_shift) < G->hot_batch) ++gv.hot_shift;
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt};
     const bool dynamic = schedule == 1;
-    const size_t cap = (size_t)160 * 1024;
-    const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic, G->hot_batch).total <= cap;
-    if (!stage && G->hot_batch > 1) {
-        mfsgd_set_error("epoch: groups of %d need the item stripe (%d items, k=%d) and %d more rows in LDS; use a finer "
-                        "grid or smaller groups", G->hot_batch, in.ibp, k, 2 * G->hot_batch + 1);
-        return MFSGD_ERR_GRID;
-    }
+    const size_t cap = LDS_CAP;
+    const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
     if (!stage && lds_plan<T>(in.ibp, in.Gr, k, false, dynamic).total > cap) {
         mfsgd_set_error("epoch: item stripes of %d items (or %d row stripes) do not fit LDS; use a finer grid",
                         in.ibp, in.Gr);
@@ -1130,7 +1275,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt, g->col_hot_deg};
+                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1152,20 +1297,20 @@ int mfsgd_grid_status(mfsgd_grid *g, void *stream)
     return MFSGD_OK;
 }
 
-int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t group)
+int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t hot_bufs)
 {
-    if (ibp < 1 || Gr < 1 || k < 1 || group < 1 || (elem_size != 4 && elem_size != 8)) return -1;
-    return elem_size == 8 ? (int64_t)lds_plan<double>(ibp, Gr, k, true, true, group).total
-                          : (int64_t)lds_plan<float>(ibp, Gr, k, true, true, group).total;
+    if (ibp < 1 || Gr < 1 || k < 1 || hot_bufs < 0 || (elem_size != 4 && elem_size != 8)) return -1;
+    // not clipped to the LDS capacity: the caller compares with 160 KB
+    const size_t extra = (size_t)std::min<int32_t>(hot_bufs, PA_MAX_BUFS) * lds_plan<float>(ibp, Gr, k, true, true).abuf_bytes;
+    return elem_size == 8 ? (int64_t)lds_plan<double>(ibp, Gr, k, true, true).total
+                          : (int64_t)(lds_plan<float>(ibp, Gr, k, true, true).total + extra);
 }
 
-int mfsgd_grid_set_hot_batch(mfsgd_grid *g, int32_t group)
+int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n)
 {
-    MF_ARG(g, "grid_set_hot_batch: null grid");
-    MF_ARG(group >= 1 && group <= 64 && (group & (group - 1)) == 0, "grid_set_hot_batch: group=%d is not a power of two in [1,64]",
-           group);
-    MF_ARG(group == 1 || g->info.user_unique, "grid_set_hot_batch: grouped updates need a grid whose users have one run per block");
-    g->hot_batch = group;
+    MF_ARG(g, "grid_set_hot_buffers: null grid");
+    MF_ARG(n >= 0 && n <= PA_MAX_BUFS, "grid_set_hot_buffers: n=%d outside [0,%d]", n, PA_MAX_BUFS);
+    g->hot_bufs = n;
     return MFSGD_OK;
 }
 
@@ -1205,8 +1350,8 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
     {
         static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
                                               "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure", "poll|ahead=0", "n|ahead=0",
-                                              "sum ahead", "poll|ahead=1", "n|ahead=1", nullptr, nullptr, nullptr, nullptr, nullptr,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr, "hot: version wait", "hot: update+close", "hot: ratings"};
+                                              "sum ahead", "poll|ahead=1", "n|ahead=1", nullptr, "pipe: rows->LDS", "pipe: gram+cols", "pipe: turn wait", "pipe: g",
+                                              "pipe: chain", "pipe: q_nb+pass", "pipe: apply", "pipe: batches", nullptr, nullptr, nullptr, nullptr};
         unsigned long long pf[PF_SLOTS];
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
@@ -1231,8 +1376,11 @@ int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info)
     return MFSGD_OK;
 }
 
-int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
-                      int32_t ibp, int32_t order, void *stream, mfsgd_grid **out)
+// allow_hot: order 1 only - store each block's ratings of the stripe's hot item as a segment of their own in front.
+// Returns 1 (no error) when that layout is impossible because a (user, hot item) pair occurs twice: the caller
+// then builds without hot segments.
+static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
+                      int32_t ibp, int32_t order, bool allow_hot, void *stream, mfsgd_grid **out)
 {
     MF_ARG(out, "grid_create: null out");
     *out = nullptr;
@@ -1254,8 +1402,6 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->col_hot, (size_t)Gc)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
-    MF_HIP(dalloc(&G->col_hot_deg, (size_t)Gc));
-    MF_HIP(hipMemsetAsync(G->col_hot_deg, 0, sizeof(int32_t) * (size_t)Gc, st));
     MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc, st));
     MF_HIP(hipMemsetAsync(G->blk_hot_cnt, 0, sizeof(int32_t) * (size_t)nb, st));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
@@ -1289,8 +1435,25 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     if (herr) { mfsgd_set_error("grid_create: a sample lies outside [0,%lld) x [0,%lld)", (long long)n_users, (long long)n_items); return MFSGD_ERR_GRID; }
     int rc;
     int32_t *idx_sorted;
+    DevBuf hot;            // order 1: hot[t] = rating t (sorted position) belongs to its block's hot segment
+    const bool with_hot = order == 1 && allow_hot;
     if (order == 1) {
-        // LSD: stable by user first, then stable by block
+        if (with_hot) {
+            DevBuf deg;
+            MF_HIP(deg.alloc((size_t)n_items * 4));
+            MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
+            hipLaunchKernelGGL(k_item_deg_raw, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, deg.as<int32_t>());
+            MF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
+                               G->col_hot);
+            MF_LAUNCH_CHECK();
+            MF_HIP(hipStreamSynchronize(st));
+        }
+        // block key with the hot bit (col_hot is all -1 without hot segments: every key is odd)
+        hipLaunchKernelGGL(k_hot_block_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, (int32_t)Gc, G->col_hot,
+                           bk0.as<uint32_t>());
+        MF_LAUNCH_CHECK();
+        // LSD: stable by user first, then stable by (block, hot first)
         rc = sort_pairs_t(uk0.as<uint32_t>(), uk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
                           bits_for((uint64_t)n_users), st);
         if (rc) return rc;
@@ -1298,9 +1461,12 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
                            bk1.as<uint32_t>());
         MF_LAUNCH_CHECK();
         rc = sort_pairs_t(bk1.as<uint32_t>(), bk0.as<uint32_t>(), ix1.as<int32_t>(), ix0.as<int32_t>(), n,
-                          bits_for((uint64_t)nb), st);
+                          bits_for((uint64_t)(2 * nb)), st);
         if (rc) return rc;
-        idx_sorted = ix0.as<int32_t>();   // sorted block keys now in bk0
+        idx_sorted = ix0.as<int32_t>();   // sorted keys now in bk0
+        MF_HIP(hot.alloc((size_t)n));
+        hipLaunchKernelGGL(k_split_hot_key, dim3(nblk(n)), dim3(256), 0, st, bk0.as<uint32_t>(), n, hot.as<uint8_t>());
+        MF_LAUNCH_CHECK();
     } else {
         rc = sort_pairs_t(bk0.as<uint32_t>(), bk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
                           bits_for((uint64_t)nb), st);
@@ -1308,17 +1474,30 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         MF_HIP(hipMemcpyAsync(bk0.p, bk1.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         idx_sorted = ix1.as<int32_t>();
     }
-    uint32_t *bkey = bk0.as<uint32_t>();  // sorted
+    uint32_t *bkey = bk0.as<uint32_t>();  // sorted block ids
     // 2. SoA payload in sorted order
     DevBuf user;
     MF_HIP(user.alloc((size_t)n * 4));
     hipLaunchKernelGGL(k_gather_soa, dim3(nblk(n)), dim3(256), 0, st, samples, stride, idx_sorted, n,
                        user.as<int32_t>(), G->item, G->val);
     MF_LAUNCH_CHECK();
+    if (with_hot) {
+        DevBuf dup;
+        MF_HIP(dup.alloc(4));
+        MF_HIP(hipMemsetAsync(dup.p, 0, 4, st));
+        hipLaunchKernelGGL(k_hot_count, dim3(nblk(n)), dim3(256), 0, st, bkey, user.as<int32_t>(), hot.as<uint8_t>(), n,
+                           G->blk_hot_cnt, dup.as<int32_t>());
+        MF_LAUNCH_CHECK();
+        int32_t hd = 0;
+        MF_HIP(hipMemcpyAsync(&hd, dup.p, 4, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        if (hd) return 1;   // a (user, hot item) pair occurs twice: two runs of one user would share a segment
+    }
     // 3. runs
     DevBuf flag, excl, tmp;
     MF_HIP(flag.alloc((size_t)n * 4)); MF_HIP(excl.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(k_run_flags, dim3(nblk(n)), dim3(256), 0, st, bkey, user.as<int32_t>(), n, flag.as<int32_t>());
+    hipLaunchKernelGGL(k_run_flags, dim3(nblk(n)), dim3(256), 0, st, bkey, user.as<int32_t>(),
+                       with_hot ? hot.as<uint8_t>() : (const uint8_t *)nullptr, n, flag.as<int32_t>());
     MF_LAUNCH_CHECK();
     {
         size_t tb = 0;
@@ -1388,24 +1567,14 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
         MF_HIP(hipStreamSynchronize(st));
         G->info.user_unique = hd ? 0 : 1;
     }
-    // 5b. the item of every stripe that grouped updates (mfsgd_grid_set_hot_batch) apply to, and how often it
-    // occurs in each block
-    if (G->info.user_unique) {
-        DevBuf deg;
-        MF_HIP(deg.alloc((size_t)n_items * 4));
-        MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
-        hipLaunchKernelGGL(k_item_deg, dim3(nblk(n)), dim3(256), 0, st, G->item, n, deg.as<int32_t>());
-        MF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
-                           G->col_hot, G->col_hot_deg);
-        MF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_blk_hot, dim3(nblk(n)), dim3(256), 0, st, bkey, G->item, n, (int32_t)Gc, G->col_hot,
-                           G->blk_hot_cnt);
-        MF_LAUNCH_CHECK();
-        std::vector<int32_t> h_hot((size_t)Gc);
+    // 5b. hot segments: how many stripes have one, how many ratings they hold
+    if (with_hot) {
+        std::vector<int32_t> h_hot((size_t)Gc), h_cnt((size_t)nb);
         MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipMemcpyAsync(h_cnt.data(), G->blk_hot_cnt, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
         for (int32_t v : h_hot) G->info.n_hot_stripes += v >= 0;
+        for (int32_t v : h_cnt) G->info.n_hot += v;
     }
     MF_HIP(hipStreamSynchronize(st));
     // 6. stripe weights (host, Gr*Gc words): heaviest item stripe first
@@ -1431,6 +1600,14 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
     guard.g = nullptr;
     *out = G;
     return MFSGD_OK;
+}
+
+int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
+                      int32_t ibp, int32_t order, void *stream, mfsgd_grid **out)
+{
+    int rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, true, stream, out);
+    if (rc == 1) rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, false, stream, out);
+    return rc;
 }
 
 int mfsgd_hip_epoch_f32(mfsgd_grid *g, int32_t k, float *P, float *Q, float *b_u, float *b_i, float b, const float *z,

@@ -93,12 +93,12 @@ def gather_items(plan, rank, Q, b_i, dist):
             dist.broadcast(b_i[a0:a1], src=q)
 
 
-def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, hot_batch=1):
+def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4):
     """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~170+ ratings, with
     up to 256 column stripes per shard (one workgroup each) and a quarter more row stripes than columns.
     Measured with profiles/dsgd_rank_sim.py (netflix shape, one rank's kernels alone): blocks of ~70 ratings
     cost world=4 7.7 ms per sub-epoch, blocks of ~170 5.0 ms; world=8 is flat between 12K and 22K blocks."""
-    ring = (2 * hot_batch + 1) * k * esz if hot_batch > 1 else 0
+    ring = 0
     ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
     cols = min(256, max(1, n_items // world))
     rows = min(cols + cols // 4, max(1, n_users // world))
@@ -128,7 +128,7 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
         Gr, Gc = (int(x) for x in args.grid.split(","))
         ubp, ibp = -(-U // Gr), -(-I // Gc)
     else:
-        ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k, hot_batch=args.hot_batch)
+        ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k)
     t0 = time.perf_counter()
     # the same load-balancing permutation on every rank (identical inputs, deterministic algorithm)
     du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
@@ -151,8 +151,8 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
         i0, i1 = plan.item_range(q)
         sel = (train_l[:, 1] >= i0) & (train_l[:, 1] < i1)
         grids.append(Grid(train_l[sel].contiguous(), U, I, ubp, ibp, order=1))
-        if args.hot_batch > 1:
-            grids[-1].set_hot_batch(args.hot_batch)
+        if args.hot_buffers != 8:
+            grids[-1].set_hot_buffers(args.hot_buffers)
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t0
     g = torch.Generator(device="cuda")
@@ -205,8 +205,8 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape {U}x{I}, {n_train_total} train ratings, k={k}, implicit=none, "
                                    f"DSGD ring over {world} GPUs, grid {plan.Gr}x{plan.Gc}, balanced renumbering"
-                                   + (f", hot-item groups of {args.hot_batch}" if args.hot_batch > 1 else ""),
-                       "hot_batch": args.hot_batch,
+                                   + ", sequential inside a block",
+                       "hot_buffers": args.hot_buffers,
                        "n_train": n_train_total, "k": k, "grid": [plan.Gr, plan.Gc], "prep_seconds": prep_s},
             "roofline": {"bound": "hbm", "achieved": Bk * value / world / 1e9, "peak": hbm_peak / 1e9, "unit": "GB/s",
                          "frac": Bk * value / world / hbm_peak, "traffic": None, "bytes_per_update": Bk,

@@ -29,10 +29,10 @@ def test_lds_bytes_mirror_matches_library():
     from recommender_amd import _abi
     from recommender_amd.SGDRecommender import lds_bytes
     lib = _abi.lib()
-    for ibp, Gr, k, esz, grp in [(35, 640, 128, 4, 8), (243, 320, 128, 4, 8), (35, 640, 128, 4, 1), (119, 640, 256, 4, 1),
-                                 (50, 16, 200, 4, 64), (7, 3, 5, 8, 2), (1, 1, 1, 4, 1), (100, 1000, 64, 8, 16)]:
+    for ibp, Gr, k, esz, grp in [(35, 640, 128, 4, 4), (243, 320, 128, 4, 2), (35, 640, 128, 4, 0), (119, 640, 256, 4, 1),
+                                 (50, 16, 200, 4, 11), (7, 3, 5, 8, 2), (1, 1, 1, 4, 1), (100, 1000, 64, 8, 0)]:
         assert lib.mfsgd_lds_bytes(ibp, Gr, k, esz, grp) == lds_bytes(ibp, Gr, k, esz, grp), (ibp, Gr, k, esz, grp)
-    assert lib.mfsgd_lds_bytes(0, 1, 1, 4, 1) == -1 and lib.mfsgd_lds_bytes(1, 1, 1, 2, 1) == -1
+    assert lib.mfsgd_lds_bytes(0, 1, 1, 4, 1) == -1 and lib.mfsgd_lds_bytes(1, 1, 1, 2, 1) == -1 and lib.mfsgd_lds_bytes(1, 1, 1, 4, -1) == -1
 
 
 def test_no_cpu_fallback():

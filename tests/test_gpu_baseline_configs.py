@@ -4,9 +4,9 @@ generator and seeds bench.py uses), through the C-ABI.
  * ML-1M shape, k=64: the free-block schedule's logged block order replayed rating by rating on the CPU oracle
    reproduces the GPU factors (1e-4 relative, north_star's bar for the factors).
  * ML-25M shape, k=128: north_star's held-out-RMSE gate.  Same data, same id space, same initial factors, same
-   epochs: the deterministic fixed-order run on the reference's (n_threads+1)^2 grid, the free-block schedule with
-   the reference's order inside a block, and the free-block schedule with grouped hot-item updates agree pairwise
-   to 0.002 in held-out RMSE.  One epoch of the free-block run is also replayed on the oracle.
+   epochs: the deterministic fixed-order run on the reference's (n_threads+1)^2 grid and the free-block schedule
+   (hot segments through the item tickets, and through the hot-item pipeline) agree pairwise to 0.002 in held-out
+   RMSE on the trained model.  One epoch of each free-block run is also replayed on the oracle.
  * Netflix shape k=128 and Yahoo!Music shape k=256: size-independent properties - every non-empty block issued
    exactly once per epoch, no bounded wait ran out, block sizes sum to n, the tickets of a sampled block are the
    ranks of its ratings per item, train and held-out RMSE fall epoch after epoch.
@@ -43,14 +43,14 @@ def orc():
     return oracle
 
 
-def _model(ra, name, *, hot_batch=1, deterministic=False, n_threads=15, renumber="balanced", grid=None, k=None,
+def _model(ra, name, *, hot_buffers=None, deterministic=False, n_threads=15, renumber="balanced", grid=None, k=None,
            init_seed=1):
     """ExplicitMF on the named workload: data generated on the GPU, ids renumbered, grid built, factors drawn."""
     import torch
     import workloads
     train, test, U, I, kk = workloads.synth(torch, name)
     m = ra.ExplicitMF(n_threads=n_threads, n_factors=k or kk, alpha=HP[0], beta1=HP[1], beta2=HP[2], implicit="none",
-                      deterministic=deterministic, hot_batch=hot_batch, grid=grid, verbose=False)
+                      deterministic=deterministic, hot_buffers=hot_buffers, grid=grid, verbose=False)
     m.load_samples_from_device(train, test, U, I)
     np.random.seed(20240611)
     if renumber == "balanced":
@@ -75,21 +75,21 @@ def _check_order_log(log, g, blk_run_ptr):
         assert issued[:, 0].max() < Gr and issued[:, 1].max() < Gc
 
 
-def _replay(orc, m, g, log, P, Q, bu, bi, hot_batch=1):
-    """Replay the logged block order on the CPU oracle, in place on the given host factors."""
+def _replay(orc, m, g, log, P, Q, bu, bi):
+    """Replay the logged block order on the CPU oracle's plain sequential kernel, in place on the given host factors;
+    inside a block the grid's stored order (tests/_order.py: hot segment first, then by user)."""
+    from _order import stored_order
     s = m._d_samples.cpu().numpy()
     Gc, ubp, ibp = g.info.Gc, g.info.ubp, g.info.ibp
-    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
-    order = np.lexsort((s[:, 0], key))          # stable: block, then user, then input order (= order 1 of the grid)
-    ss, ks = s[order], key[order]
+    perm, key, hot = stored_order(s, ubp, ibp, Gc, g.col_hot())
+    assert int(hot.sum()) == g.info.n_hot
+    ss, ks = s[perm], key[perm]
     ptr = np.searchsorted(ks, np.arange(g.info.Gr * Gc + 1))
-    col_hot = g.col_hot() if hot_batch > 1 else np.full(Gc, -1)
     for e in range(log.shape[0]):
         for r, c in log[e]:
             if r < 0:
                 continue
-            orc.sgd(P, Q, bu, bi, m.b, None, ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]], None, None, *HP, implicit=0,
-                    hot_item=int(col_hot[c]), hot_batch=hot_batch)
+            orc.sgd(P, Q, bu, bi, m.b, None, ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]], None, None, *HP, implicit=0)
 
 
 def _host_factors(m):
@@ -114,51 +114,70 @@ def test_ml1m_k64_full_size_replays_on_oracle(ra, orc):
 
 
 # ------------------------------------------------------------------ config 3: ML-25M shape, k=128 - the RMSE gate
-def test_ml25m_k128_rmse_gate_fixed_vs_free_vs_grouped(ra, orc):
+def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
     """north_star: 'held-out RMSE must match within 0.002'.  The reference's own parallel run is any conflict-free
-    block order with a sequential pass inside each block (RayBlockScheduler.py:148-181, :58)."""
+    block order with a sequential pass inside each block (RayBlockScheduler.py:148-181, :58).
+
+    Three runs on the full-size shape, same data, same id space (the reference's random shuffle under one seed),
+    same initial factors, same number of epochs at the reference's constant alpha = 0.006:
+      fixed     deterministic=True: the reference's 16 x 16 grid, file order inside a block, row-major block order;
+      tickets   on-GPU free-block schedule on the throughput grid, every rating through the item tickets;
+      pipeline  the same schedule with the hot segments on the hot-item pipeline (the default).
+    All three are sequential inside a block; they differ in the block grid and the block order only.
+    The gate is asserted on the trained model: at every epoch of the last quarter.
+    profiles/r2_rmse_parity.txt holds 30-epoch trajectories (profiles/rmse_gate.py): on the plateau the orders agree to
+    3e-4; WHILE the model leaves the small-initialisation saddle (epochs 2-8 here) the free-block curves run ~0.15
+    epoch behind the fixed order (up to 0.015 apart at epoch 3) - a shift in time, not in where they arrive.
+    One epoch of each free-block run is also replayed on the CPU oracle (factors to 1e-4)."""
     import torch
-    epochs = 6
-    runs = {}
-    # same id space (the reference's random shuffle under one seed) and the same initial factors for the three runs
+    epochs = 16
+    tail = 4
+    runs, grids = {}, {}
     for tag, kw in (("fixed", dict(deterministic=True, n_threads=15, renumber="random")),
-                    ("free", dict(hot_batch=1, renumber="random")),
-                    ("grouped", dict(hot_batch=8, renumber="random"))):
+                    ("tickets", dict(hot_buffers=0, renumber="random", grid=(288, 512))),
+                    ("pipeline", dict(renumber="random", grid=(288, 512)))):
         m, g = _model(ra, "ml25m", **kw)
         assert m.n_factors == 128
         if tag == "fixed":
-            assert (g.info.Gr, g.info.Gc, g.info.order) == (16, 16, 0)
-        before = m.device_errors()
+            assert (g.info.Gr, g.info.Gc, g.info.order, g.info.n_hot) == (16, 16, 0, 0)
+        traj = [m.device_errors()]
         ref = log = None
-        if tag == "free":
+        if tag != "fixed":
             ref = _host_factors(m)
             log = torch.full((g.info.Gr * g.info.Gc, 2), -1, dtype=torch.int32, device="cuda")
         m.run_epochs(1, order_log=log)
-        if tag == "free":
+        if tag != "fixed":
             g.status()
             log = log.cpu().numpy().reshape(1, -1, 2)
             _check_order_log(log, g, g.export_device()["blk_run_ptr"].cpu().numpy())
             _replay(orc, m, g, log, *ref)
             for name, r_ in zip(("P", "Q", "b_u", "b_i"), ref):
-                assert relerr(m._dev[name].cpu().numpy(), r_.astype(np.float64)) <= 1e-4, name
-        m.run_epochs(epochs - 1)
-        runs[tag] = (before, m.device_errors(), (g.info.Gr, g.info.Gc))
+                assert relerr(m._dev[name].cpu().numpy(), r_.astype(np.float64)) <= 1e-4, (tag, name)
+        traj.append(m.device_errors())
+        for _ in range(epochs - 1):
+            m.run_epochs(1)
+            traj.append(m.device_errors())
+        runs[tag], grids[tag] = traj, (g.info.Gr, g.info.Gc, int(g.info.n_hot))
         del m, g
         torch.cuda.empty_cache()
-    for tag, (b0, b1, gr) in runs.items():
-        print(f"ml25m k=128 {tag:8s} grid {gr[0]}x{gr[1]}: train {b0[0]:.5f} -> {b1[0]:.5f}  held-out {b0[1]:.5f} -> {b1[1]:.5f}")
-    assert runs["fixed"][0] == runs["free"][0] == runs["grouped"][0]          # same start
-    assert runs["fixed"][1][1] < runs["fixed"][0][1] - 0.05                   # it learned
-    for a, b in (("fixed", "free"), ("fixed", "grouped"), ("free", "grouped")):
-        assert abs(runs[a][1][1] - runs[b][1][1]) < 0.002, (a, b, runs[a][1], runs[b][1])
-        assert abs(runs[a][1][0] - runs[b][1][0]) < 0.002, (a, b, runs[a][1], runs[b][1])
+    for tag, traj in runs.items():
+        print(f"ml25m k=128 {tag:8s} grid {grids[tag][0]}x{grids[tag][1]} ({grids[tag][2]} ratings in hot segments): "
+              "held-out " + " ".join(f"{te:.4f}" for _, te in traj))
+    assert runs["fixed"][0] == runs["tickets"][0] == runs["pipeline"][0]      # same start
+    assert runs["fixed"][-1][1] < runs["fixed"][0][1] - 0.4                   # trained: 1.059 -> ~0.608
+    for a, b in (("fixed", "tickets"), ("fixed", "pipeline"), ("tickets", "pipeline")):
+        for e in range(epochs - tail + 1, epochs + 1):
+            assert abs(runs[a][e][1] - runs[b][e][1]) < 0.002, (a, b, e, runs[a][e], runs[b][e])
+            assert abs(runs[a][e][0] - runs[b][e][0]) < 0.002, (a, b, e, runs[a][e], runs[b][e])
+    # the two ways through a hot segment are the same computation: never more than 5e-4 apart, transient included
+    assert max(abs(x[1] - y[1]) for x, y in zip(runs["tickets"], runs["pipeline"])) < 5e-4
 
 
 # ------------------------------------------------------------------ configs 4 and 5: full-size properties
-@pytest.mark.parametrize("name,k,hot_batch", [("netflix", 128, 1), ("netflix", 128, 8), ("yahoo", 256, 1)])
-def test_full_size_properties(ra, name, k, hot_batch):
+@pytest.mark.parametrize("name,k,hot_buffers", [("netflix", 128, 8), ("netflix", 128, 0), ("yahoo", 256, 8)])
+def test_full_size_properties(ra, name, k, hot_buffers):
     import torch
-    m, g = _model(ra, name, hot_batch=hot_batch)
+    m, g = _model(ra, name, hot_buffers=hot_buffers)
     assert m.n_factors == k
     n = int(m._d_samples.shape[0])
     assert g.info.n == n and g.info.user_unique == 1
@@ -169,7 +188,8 @@ def test_full_size_properties(ra, name, k, hot_batch):
     blk_ptr = run_start[torch.from_numpy(brp.astype(np.int64)).cuda()].cpu().numpy()     # rating offsets of the blocks
     sizes = np.diff(blk_ptr)
     assert sizes.min() >= 0 and sizes.sum() == n and sizes.max() == g.info.max_block
-    # a sampled block (the largest): its ratings lie in the block, users ascend, tickets are per-item ranks
+    # a sampled block (the largest): its ratings lie in the block, the hot segment comes first with one rating per
+    # user, users ascend inside each segment, tickets are per-item ranks
     bsel = int(np.argmax(sizes))
     a, b_ = int(blk_ptr[bsel]), int(blk_ptr[bsel + 1])
     items = d["item"][a:b_].cpu().numpy()
@@ -177,7 +197,10 @@ def test_full_size_properties(ra, name, k, hot_batch):
     r_, c_ = divmod(bsel, g.info.Gc)
     assert items.min() >= c_ * g.info.ibp and items.max() < (c_ + 1) * g.info.ibp
     ru = d["run_user"][int(brp[bsel]):int(brp[bsel + 1])].cpu().numpy()
-    assert (np.diff(ru) > 0).all() and ru.min() >= r_ * g.info.ubp and ru.max() < (r_ + 1) * g.info.ubp
+    hot_item = int(g.col_hot()[c_])
+    nh = int((items == hot_item).sum())
+    assert (items[:nh] == hot_item).all() and (np.diff(ru[:nh]) > 0).all() and (np.diff(ru[nh:]) > 0).all()
+    assert ru.min() >= r_ * g.info.ubp and ru.max() < (r_ + 1) * g.info.ubp
     seen = {}
     for it, tk in zip(items.tolist(), ticks.tolist()):
         assert tk == seen.get(it, 0)
@@ -190,7 +213,7 @@ def test_full_size_properties(ra, name, k, hot_batch):
         m.run_epochs(1, order_log=log[e * g.info.Gr * g.info.Gc:])
         errs.append(m.device_errors())          # device_errors() checks grid.status() first
     _check_order_log(log.cpu().numpy().reshape(epochs, -1, 2), g, brp)
-    print(f"{name} k={k} hot_batch={hot_batch} grid {g.info.Gr}x{g.info.Gc}: " +
+    print(f"{name} k={k} hot_buffers={hot_buffers} grid {g.info.Gr}x{g.info.Gc}, {int(g.info.n_hot)} ratings in hot segments: " +
           "  ".join(f"{tr:.4f}/{te:.4f}" for tr, te in errs))
     for (tr0, te0), (tr1, te1) in zip(errs[:-1], errs[1:]):
         assert tr1 < tr0 and te1 < te0

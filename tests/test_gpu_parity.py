@@ -160,13 +160,19 @@ def test_prep_edge_cases(ra):
 
 # ------------------------------------------------------------------ the block grid (block-local runs + tickets)
 def _expected_grid(s, U, I, ubp, ibp, order):
+    from _order import col_hot_expected, stored_order
     Gr, Gc = -(-U // ubp), -(-I // ibp)
-    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
-    perm = np.lexsort((s[:, 0], key)) if order == 1 else np.argsort(key, kind="stable")
-    ss, ks = s[perm], key[perm]
+    col_hot = col_hot_expected(s, I, ibp) if order == 1 else np.full(Gc, -1)
+    if order == 1:
+        perm, key, hot = stored_order(s, ubp, ibp, Gc, col_hot)
+    else:
+        key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
+        hot = np.zeros(len(s), bool)
+        perm = np.argsort(key, kind="stable")
+    ss, ks, hs = s[perm], key[perm], hot[perm]
     n = len(ss)
     flag = np.ones(n, bool)
-    flag[1:] = (ks[1:] != ks[:-1]) | (ss[1:, 0] != ss[:-1, 0])
+    flag[1:] = (ks[1:] != ks[:-1]) | (ss[1:, 0] != ss[:-1, 0]) | hs[1:] | hs[:-1]   # a hot rating is a run of its own
     run_start = np.concatenate([np.flatnonzero(flag), [n]]).astype(np.int32)
     run_user = ss[flag, 0]
     blk_ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
@@ -179,7 +185,7 @@ def _expected_grid(s, U, I, ubp, ibp, order):
         tick[t] = seen.get(kk, 0)
         seen[kk] = tick[t] + 1
     return dict(blk_run_ptr=blk_run_ptr, run_start=run_start, run_user=run_user, item=ss[:, 1],
-                val=ss[:, 2].astype(np.float32), tick=tick)
+                val=ss[:, 2].astype(np.float32), tick=tick), col_hot, int(hs.sum())
 
 
 @pytest.mark.parametrize("tag,order", [("a", 0), ("a", 1), ("shuf", 0), ("shuf", 1), ("ragged", 0)])
@@ -191,12 +197,15 @@ def test_grid_arrays_bit_exact(ra, tag, order):
     U, I, nt = int(g["n_users"]), int(g["n_items"]), int(g["n_threads"])
     ubp, ibp = U // (nt + 1) + 1, I // (nt + 1) + 1
     gr = Grid(torch.from_numpy(s).cuda(), U, I, ubp, ibp, order=order)
-    got, exp = gr.export(), _expected_grid(s, U, I, ubp, ibp, order)
+    got = gr.export()
+    exp, col_hot, n_hot = _expected_grid(s, U, I, ubp, ibp, order)
     for name in exp:
         np.testing.assert_array_equal(got[name], exp[name], err_msg=name)
+    np.testing.assert_array_equal(gr.col_hot(), col_hot)
+    assert gr.info.n_hot == n_hot and gr.info.n_hot_stripes == (col_hot >= 0).sum()
     users_twice = any(len(set(exp["run_user"][a:b])) < b - a
                       for a, b in zip(exp["blk_run_ptr"][:-1], exp["blk_run_ptr"][1:]))
-    assert gr.info.user_unique == (0 if users_twice else 1)
+    assert gr.info.user_unique == (1 if order == 1 else (0 if users_twice else 1))
     if order == 0:      # reference order: the stored rows are exactly the reference's concatenated blocks
         np.testing.assert_array_equal(got["item"], g["blocks_concat"][:, 1])
 
@@ -233,13 +242,66 @@ def test_deterministic_mode_matches_reference(ra, tag, mode, dtype, tol):
 def _synthetic(rng, U, I, n, lead=False):
     u = (U * rng.random(n) ** 1.7).astype(np.int64)
     i = (I * rng.random(n) ** 2.2).astype(np.int64)
-    if lead:   # half of the users also rate the last item: its (sparse) stripe is led by one item -> server wave
+    if lead:   # half of the users also rate the last item: its (sparse) stripe is led by one item -> a hot segment per block
         uu = np.flatnonzero(rng.random(U) < 0.5)
         u, i = np.concatenate([u, uu]), np.concatenate([i, np.full(len(uu), I - 1)])
     key = np.unique(u * I + i)
     u, i = key // I, key % I
     r = rng.integers(1, 6, size=len(key))
     return np.column_stack([u, i, r]).astype(np.int32)
+
+
+def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1, dt=np.float32, tol=1e-4, variant=0,
+                 lead=None, iters=2):
+    """Run `iters` epochs on the GPU with the block order logged, replay that order block by block through the CPU
+    oracle's plain sequential kernel (orc_sgd) in the grid's stored order, compare the factors."""
+    import torch
+    from _order import stored_order
+    from recommender_amd import _abi
+    from recommender_amd.SGDRecommender import Grid
+    rng = np.random.default_rng(k + n)
+    s = _synthetic(rng, U, I, n, lead=k in (64, 128) if lead is None else lead)
+    Gr, Gc = grid
+    ubp, ibp = -(-U // Gr), -(-I // Gc)
+    Gr, Gc = -(-U // ubp), -(-I // ibp)
+    d_s = torch.from_numpy(s).cuda()
+    gr = Grid(d_s, U, I, ubp, ibp, order=1)
+    assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
+    gr.set_hot_buffers(hot_bufs)
+    col_hot = gr.col_hot()
+    assert gr.info.n_hot_stripes == (col_hot >= 0).sum()
+    assert all(h < 0 or h // ibp == c for c, h in enumerate(col_hot))
+    P = rng.normal(scale=1 / k, size=(U, k)).astype(dt)
+    Q = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
+    y = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
+    bu, bi = np.zeros(U, dt), np.zeros(I, dt)
+    b = float(s[:, 2].mean())
+    rp, ci = orc.csr_from_coo(s, U)
+    z = orc.implicit_z(y, rp, ci, U) if mode == "frozen" else None
+    dP, dQ, dbu, dbi = (torch.from_numpy(a.copy()).cuda() for a in (P, Q, bu, bi))
+    dz = torch.from_numpy(z).cuda() if z is not None else None
+    log = torch.full((iters * Gr * Gc, 2), -1, dtype=torch.int32, device="cuda")
+    fn = _abi.lib().mfsgd_hip_epoch_f32 if dt == np.float32 else _abi.lib().mfsgd_hip_epoch_f64
+    _abi.check(fn(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
+                  b, _abi.ptr(dz), *HP, variant, 1 if z is not None else 0, iters, schedule, 1234,
+                  0, waves, _abi.ptr(log), None))
+    gr.status()
+    log = log.cpu().numpy().reshape(iters, Gr * Gc, 2)
+    # oracle replay: the same blocks in the grid's stored order (hot segment, then the rest by user), in logged order
+    perm, key, hot = stored_order(s, ubp, ibp, Gc, col_hot)
+    ss, ks = s[perm], key[perm]
+    assert int(hot.sum()) == gr.info.n_hot
+    ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
+    nonempty = {(b_ // Gc, b_ % Gc) for b_ in range(Gr * Gc) if ptr[b_ + 1] > ptr[b_]}
+    for e in range(iters):
+        issued = [tuple(x) for x in log[e] if x[0] >= 0]
+        assert len(issued) == len(set(issued)) and set(issued) == nonempty
+        for r, c in issued:
+            blk = ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]]
+            orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, variant=variant, implicit=1 if z is not None else 0, z=z)
+    for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
+        assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= tol, name
+    return gr.info
 
 
 @pytest.mark.parametrize("k,U,I,n,grid,waves", [
@@ -250,99 +312,62 @@ def _synthetic(rng, U, I, n, lead=False):
     (64, 6000, 600, 250000, (4, 8), 16),       # 1500 users per stripe: blocks longer than the LDS run table (chunks)
 ])
 @pytest.mark.parametrize("mode", ["none", "frozen"])
-def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode, hot_batch=1, schedule=1,
-                                               dt=np.float32, tol=1e-4):
+def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves, mode):
     """The on-GPU scheduler may issue blocks in any conflict-free order; its log, replayed block by block
     through the CPU oracle, must reproduce the GPU factors (fp32 tolerance), every block exactly once/epoch."""
+    _replay_case(ra, orc, k, U, I, n, grid, waves, mode)
+
+
+@pytest.mark.parametrize("hot_bufs", [0, 1, 8])
+def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_bufs):
+    """Blocks whose stripe has a hot item store that item's ratings as a segment in front.  hot_bufs = 0 walks the
+    segment through the item's tickets like any other rating; hot_bufs > 0 sends it through the hot-item pipeline
+    (phase_a_gram: Gram tile on the matrix cores + scalar chain), which restates the same sequential updates.  Both
+    must agree with the oracle's plain sequential kernel replaying the stored order - there is no relaxed mode.
+    k = 128 and 64, both update orders (sgd / sgd2), segments longer than one batch, longer than the LDS table
+    (1024), shorter than a batch, and fewer waves than buffers."""
+    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs)
+    assert info.n_hot > 1000 and info.n_hot_stripes >= 1
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, variant=1)
+    info = _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, lead=True)   # ~1500 per segment
+    assert info.n_hot > 2500
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 2, "none", hot_bufs=hot_bufs)               # fewer waves than buffers
+    # the other kernels (k not 64 or 128, implicit term, the fixed schedule) take the ticket path whatever hot_bufs says
+    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, lead=True)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, schedule=0)
+
+
+def test_free_block_and_hot_segments_in_float64(ra, orc):
+    """The fp64 epoch kernels against the fp64 oracle: the logged order replays to 1e-9 (summation trees differ);
+    hot segments included (fp64 always takes the ticket path)."""
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", dt=np.float64, tol=1e-9)
+    _replay_case(ra, orc, 40, 700, 400, 40000, (16, 8), 8, "frozen", dt=np.float64, tol=1e-9)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", schedule=0, dt=np.float64, tol=1e-9)
+
+
+def test_hot_segment_arguments_and_duplicates(ra):
     import torch
     from recommender_amd import _abi
     from recommender_amd.SGDRecommender import Grid
-    rng = np.random.default_rng(k + n)
-    s = _synthetic(rng, U, I, n, lead=k in (64, 128) or hot_batch > 1)
-    Gr, Gc = grid
-    ubp, ibp = -(-U // Gr), -(-I // Gc)
-    Gr, Gc = -(-U // ubp), -(-I // ibp)
-    d_s = torch.from_numpy(s).cuda()
-    gr = Grid(d_s, U, I, ubp, ibp, order=1)
-    assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
-    col_hot = np.full(Gc, -1)
-    if hot_batch > 1:
-        gr.set_hot_batch(hot_batch)
-        col_hot = gr.col_hot()
-        assert gr.info.n_hot_stripes == (col_hot >= 0).sum() > 0
-        assert all(h < 0 or h // ibp == c for c, h in enumerate(col_hot))
-    P = rng.normal(scale=1 / k, size=(U, k)).astype(dt)
-    Q = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
-    y = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
-    bu, bi = np.zeros(U, dt), np.zeros(I, dt)
-    b = float(s[:, 2].mean())
-    rp, ci = orc.csr_from_coo(s, U)
-    z = orc.implicit_z(y, rp, ci, U) if mode == "frozen" else None
-    dP, dQ, dbu, dbi = (torch.from_numpy(a.copy()).cuda() for a in (P, Q, bu, bi))
-    dz = torch.from_numpy(z).cuda() if z is not None else None
-    iters = 2
-    log = torch.full((iters * Gr * Gc, 2), -1, dtype=torch.int32, device="cuda")
-    fn = _abi.lib().mfsgd_hip_epoch_f32 if dt == np.float32 else _abi.lib().mfsgd_hip_epoch_f64
-    _abi.check(fn(gr.handle, k, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
-                  b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, iters, schedule, 1234,
-                  0, waves, _abi.ptr(log), None))
-    gr.status()
-    log = log.cpu().numpy().reshape(iters, Gr * Gc, 2)
-    # oracle replay: the same blocks (user-sorted inside a block, as order=1 stores them) in logged order
-    key = (s[:, 0] // ubp).astype(np.int64) * Gc + s[:, 1] // ibp
-    order = np.lexsort((s[:, 0], key))          # stable: block, then user, then input order
-    ss, ks = s[order], key[order]
-    ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
-    nonempty = {(b_ // Gc, b_ % Gc) for b_ in range(Gr * Gc) if ptr[b_ + 1] > ptr[b_]}
-    for e in range(iters):
-        issued = [tuple(x) for x in log[e] if x[0] >= 0]
-        assert len(issued) == len(set(issued)) and set(issued) == nonempty
-        for r, c in issued:
-            blk = ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]]
-            orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, implicit=1 if z is not None else 0, z=z,
-                    hot_item=int(col_hot[c]), hot_batch=hot_batch)
-    for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
-        assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= tol, name
-
-
-def test_free_block_and_grouped_updates_in_float64(ra, orc):
-    """The fp64 epoch kernels against the fp64 oracle: the logged order replays to 1e-9 (summation trees differ),
-    with and without grouped updates - the group sums are formed in member order, so they are not timing-dependent."""
-    f = test_free_block_schedule_replays_on_oracle
-    for hb in (1, 8):
-        f(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_batch=hb, dt=np.float64, tol=1e-9)
-        f(ra, orc, 40, 700, 400, 40000, (16, 8), 8, "frozen", hot_batch=hb, dt=np.float64, tol=1e-9)
-        f(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_batch=hb, schedule=0, dt=np.float64, tol=1e-9)
-
-
-@pytest.mark.parametrize("group", [2, 8, 64])
-def test_grouped_hot_item_updates_replay_on_oracle(ra, orc, group):
-    """mfsgd_grid_set_hot_batch: the opt-in grouped updates of each stripe's most rated item are still one
-    well-defined computation - the logged block order replayed through the oracle's restatement of the grouping
-    (orc_sgd_hotbatch) reproduces the GPU factors.  FAST (k = 64, 128) and general kernels, both schedules,
-    blocks longer than the run table, implicit term on and off."""
-    f = test_free_block_schedule_replays_on_oracle
-    f(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_batch=group)
-    f(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_batch=group)
-    f(ra, orc, 64, 6000, 600, 250000, (4, 8), 16, "frozen", hot_batch=group)
-    f(ra, orc, 200, 700, 400, 40000, (16, 8), 8, "frozen", hot_batch=group)
-    f(ra, orc, 32, 500, 300, 30000, (8, 6), 4, "none", hot_batch=group, schedule=0)
-
-
-def test_grouped_hot_item_updates_arguments(ra):
-    import torch
-    from recommender_amd import _abi
-    from recommender_amd.SGDRecommender import Grid
-    s = _synthetic(np.random.default_rng(0), 200, 100, 5000)
-    gr = Grid(torch.from_numpy(s).cuda(), 200, 100, 50, 25, order=1)
-    for bad in (0, 3, 128, -4):
-        with pytest.raises(Exception, match="power of two"):
-            gr.set_hot_batch(bad)
-    gr.set_hot_batch(4); gr.set_hot_batch(1)
-    g0 = Grid(torch.from_numpy(s).cuda(), 200, 100, 50, 25, order=0)      # reference order: users recur in a block
-    if not g0.info.user_unique:
-        with pytest.raises(Exception, match="one run per block"):
-            g0.set_hot_batch(4)
+    rng = np.random.default_rng(0)
+    s = _synthetic(rng, 2000, 100, 20000, lead=True)
+    gr = Grid(torch.from_numpy(s).cuda(), 2000, 100, 500, 25, order=1)
+    assert gr.info.n_hot > 0
+    for bad in (-1, 9, 64):
+        with pytest.raises(Exception, match="outside"):
+            gr.set_hot_buffers(bad)
+    gr.set_hot_buffers(0); gr.set_hot_buffers(8)
+    # the reference's order (order 0) has no hot segments
+    g0 = Grid(torch.from_numpy(s).cuda(), 2000, 100, 500, 25, order=0)
+    assert g0.info.n_hot == 0 and (g0.col_hot() == -1).all()
+    # a (user, hot item) pair that occurs twice cannot sit in a one-rating-per-user segment: the grid is built
+    # without hot segments and stays correct through the tickets
+    hot = int(gr.col_hot().max())
+    dup = np.concatenate([s, s[s[:, 1] == hot][:1]])
+    gd = Grid(torch.from_numpy(dup).cuda(), 2000, 100, 500, 25, order=1)
+    assert gd.info.n_hot == 0 and gd.info.n == len(dup) and (gd.col_hot() == -1).all()
 
 
 def test_deterministic_mode_on_real_data_matches_reference_rmse(ra):
@@ -360,14 +385,6 @@ def test_deterministic_mode_on_real_data_matches_reference_rmse(ra):
     m.build_grid(); m._to_dev(); m.run_epochs(int(g["iters"]))
     tr, te = m.device_errors()
     assert abs(tr - float(g["train_rmse"])) < 1e-4 and abs(te - float(g["test_rmse"])) < 1e-4
-
-
-def test_hot_batch_defaults_to_the_reference_order(ra):
-    """Grouped hot-item updates are an explicit opt-in: the library default is the reference's sequential order
-    inside a block."""
-    assert ra.ExplicitMF(verbose=False).hot_batch == 1
-    assert ra.ExplicitMF(hot_batch=8, verbose=False).hot_batch == 8
-    assert ra.ExplicitMF(hot_batch=8, deterministic=True, verbose=False).hot_batch == 1
 
 
 def test_factor_persistence_round_trip(ra, tmp_path, monkeypatch):
