@@ -153,6 +153,16 @@ typedef struct {
  *          ties in input order.  If a (user, hot item) pair occurs twice the grid is built without hot segments. */
 int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                       int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
+/* The same with the hot segments at the caller's choice: a stripe's most rated item becomes its hot item only if it
+ * also has, on average, at least hot_min_per_block ratings per block of the stripe (degree >= hot_min_per_block * Gr);
+ * 0 = no hot segments at all (every block of an order-1 grid sorted by user only).  Hot segments pay when the
+ * hot-item pipeline walks them (mfsgd_grid_set_hot_buffers) in batches of 32, and cost time when they go through
+ * the item tickets (a block then starts with a stretch in which every wave waits for the same item), so a caller
+ * that knows the pipeline will not run - k other than 64 / 128, fp64, an implicit term, item stripes that leave no
+ * LDS for its row buffers - passes 0, and one that knows it will passes 32.  mfsgd_grid_create is 1 (any length). */
+int mfsgd_grid_create_opt(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
+                          int32_t ubp, int32_t ibp, int32_t order, int32_t hot_min_per_block, void *stream,
+                          mfsgd_grid **out);
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info);
 void mfsgd_grid_destroy(mfsgd_grid *g);
 /* Copies the grid's arrays into caller buffers (any may be NULL): blk_run_ptr[Gr*Gc+1], run_start[n_runs+1],

@@ -92,12 +92,14 @@ def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
 class Grid:
     """Owner of a device block grid (mfsgd_grid_*)."""
 
-    def __init__(self, d_samples, n_users, n_items, ubp, ibp, order):
+    def __init__(self, d_samples, n_users, n_items, ubp, ibp, order, hot_segments=1):
+        """hot_segments: 0 / False = none; N > 0 = a stripe's most rated item needs >= N ratings per block on average
+        (mfsgd_grid_create_opt); 1 / True = the rule of mfsgd_grid_create."""
         _abi.require_gpu()
         h = _abi.c_vp(0)
-        _abi.check(_abi.lib().mfsgd_grid_create(_abi.ptr(d_samples), int(d_samples.shape[0]), int(d_samples.shape[1]),
-                                                int(n_users), int(n_items), int(ubp), int(ibp), int(order),
-                                                _abi.stream_ptr(), _abi.C.byref(h)))
+        _abi.check(_abi.lib().mfsgd_grid_create_opt(_abi.ptr(d_samples), int(d_samples.shape[0]), int(d_samples.shape[1]),
+                                                    int(n_users), int(n_items), int(ubp), int(ibp), int(order),
+                                                    int(hot_segments), _abi.stream_ptr(), _abi.C.byref(h)))
         self.handle = h
         info = _abi.GridInfo()
         _abi.check(_abi.lib().mfsgd_grid_get_info(self.handle, _abi.C.byref(info)))
@@ -262,13 +264,28 @@ class ExplicitMF(Recommender):
         return test
 
     # ------------------------------------------------------------------ the GPU FPSGD path
+    def _pipeline_kernel(self):
+        """The hot-item pipeline exists for fp32, k = 64 or 128, no implicit term (csrc/epoch.hip, FASTA)."""
+        return (self.dtype != "float64" and self.n_factors in (64, 128) and (self.implicit or "frozen") == "none"
+                and self.hot_buffers > 0)
+
+    def _pipeline_runs(self, Gr, Gc):
+        """Will the free-block launch walk hot segments with the pipeline on a Gr x Gc grid?  It does when the kernel
+        exists, one workgroup runs per CU (launch_epochs: two share a CU when there are more stripes than CUs and two
+        stripes fit its LDS) and at least two of its row buffers fit behind the stripe (one wave alone is no pipeline)."""
+        if not self._pipeline_kernel():
+            return False
+        ibp = -(-self.n_items // Gc)
+        two_per_cu = Gc > 256 and 2 * lds_bytes(ibp, Gr, self.n_factors, 4) <= 160 * 1024
+        return not two_per_cu and lds_bytes(ibp, Gr, self.n_factors, 4, min(2, self.hot_buffers)) <= 160 * 1024
+
     def _choose_grid(self):
         """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table) in LDS, and a CU has
         160 KB of it.  One 16-wave workgroup per CU on the 128-register build is the default shape: 256 item stripes
-        (one round of the 256 CUs) whenever the stripe plus at least two row buffers of the hot-item pipeline fit, else
-        512 (two stripes per workgroup, handed out heaviest first).  User stripes: an eighth more than workgroups in
-        flight (row locks are taken at random; swept 256..320: flat, 272-288 best).  Small inputs shrink both so that
-        a block still holds ~128 ratings (per-block cost - lock, fences, barriers - is microseconds)."""
+        (one round of the 256 CUs) whenever the stripe fits, else 512 (two stripes per workgroup, handed out heaviest
+        first).  User stripes: an eighth more than workgroups in flight (row locks are taken at random; swept 256..320:
+        flat, 272-288 best).  Small inputs shrink both so that a block still holds ~128 ratings (per-block cost - lock,
+        fences, barriers - is microseconds)."""
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
@@ -277,8 +294,7 @@ class ExplicitMF(Recommender):
             n = int(self._d_samples.shape[0])
             U, I = self.n_users, self.n_items
             cap = 160 * 1024
-            pipe = esz == 4 and k in (64, 128) and self.hot_buffers > 0     # the kernels the pipeline exists for
-            fits = lambda Gr_, Gc_: lds_bytes(-(-I // Gc_), Gr_, k, esz, min(2, self.hot_buffers) if pipe else 0) <= cap
+            fits = lambda Gr_, Gc_: lds_bytes(-(-I // Gc_), Gr_, k, esz) <= cap
             if U >= 288 and I >= 256 and n >= 128 * 288 * 256 and fits(288, 256):
                 Gr, Gc = 288, 256
             elif U >= 288 and I >= 512 and n >= 128 * 288 * 512 and fits(288, 512):
@@ -309,7 +325,12 @@ class ExplicitMF(Recommender):
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=0)
         else:
             ubp, ibp = self._choose_grid()
-            self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1)
+            # hot segments only where the pipeline will walk them: through the item tickets they cost time
+            # (ML-25M shape, 288 x 256: 11.8 ms per epoch without them, 13.0 ms with)
+            # and only segments of at least one pipeline batch (32 ratings) per block on average (ML-1M shape, blocks
+            # of ~130 ratings: 1.26 ms per epoch without hot segments, 1.70 ms with)
+            hot = 32 if self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp)) else 0
+            self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)
         if self.hot_buffers != 8:
             self._grid.set_hot_buffers(self.hot_buffers)
         return self._grid

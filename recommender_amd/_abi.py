@@ -63,6 +63,7 @@ SIGNATURES = {
     "mfsgd_hip_als_step_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "mfsgd_hip_als_step_f64": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f64, c_vp]),
     "mfsgd_grid_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
+    "mfsgd_grid_create_opt": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
     "mfsgd_grid_get_info": (C.c_int, [c_vp, C.POINTER(GridInfo)]),
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

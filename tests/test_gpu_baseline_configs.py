@@ -5,7 +5,7 @@ generator and seeds bench.py uses), through the C-ABI.
    reproduces the GPU factors (1e-4 relative, north_star's bar for the factors).
  * ML-25M shape, k=128: north_star's held-out-RMSE gate.  Same data, same id space, same initial factors, same
    epochs: the deterministic fixed-order run on the reference's (n_threads+1)^2 grid and the free-block schedule
-   (hot segments through the item tickets, and through the hot-item pipeline) agree pairwise to 0.002 in held-out
+   (every rating through the item tickets, and hot segments through the hot-item pipeline) agree pairwise to 0.002 in held-out
    RMSE on the trained model.  One epoch of each free-block run is also replayed on the oracle.
  * Netflix shape k=128 and Yahoo!Music shape k=256: size-independent properties - every non-empty block issued
    exactly once per epoch, no bounded wait ran out, block sizes sum to n, the tickets of a sampled block are the
@@ -121,8 +121,8 @@ def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
     Three runs on the full-size shape, same data, same id space (the reference's random shuffle under one seed),
     same initial factors, same number of epochs at the reference's constant alpha = 0.006:
       fixed     deterministic=True: the reference's 16 x 16 grid, file order inside a block, row-major block order;
-      tickets   on-GPU free-block schedule on the throughput grid, every rating through the item tickets;
-      pipeline  the same schedule with the hot segments on the hot-item pipeline (the default).
+      tickets   on-GPU free-block schedule on a 288 x 384 grid, every rating through the item tickets (no hot segments);
+      pipeline  the same schedule and grid with hot segments, walked by the hot-item pipeline.
     All three are sequential inside a block; they differ in the block grid and the block order only.
     The gate is asserted on the trained model: at every epoch of the last quarter.
     profiles/r2_rmse_parity.txt holds 30-epoch trajectories (profiles/rmse_gate.py): on the plateau the orders agree to
@@ -134,12 +134,16 @@ def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
     tail = 4
     runs, grids = {}, {}
     for tag, kw in (("fixed", dict(deterministic=True, n_threads=15, renumber="random")),
-                    ("tickets", dict(hot_buffers=0, renumber="random", grid=(288, 512))),
-                    ("pipeline", dict(renumber="random", grid=(288, 512)))):
+                    ("tickets", dict(hot_buffers=0, renumber="random", grid=(288, 384))),
+                    ("pipeline", dict(renumber="random", grid=(288, 384)))):
         m, g = _model(ra, "ml25m", **kw)
         assert m.n_factors == 128
         if tag == "fixed":
             assert (g.info.Gr, g.info.Gc, g.info.order, g.info.n_hot) == (16, 16, 0, 0)
+        elif tag == "tickets":      # no pipeline, so the grid is built without hot segments (ExplicitMF.build_grid)
+            assert g.info.order == 1 and g.info.n_hot == 0
+        else:                       # 384 stripes of 154 items leave LDS for the pipeline's row buffers
+            assert g.info.order == 1 and g.info.n_hot > 1_000_000 and m._pipeline_runs(g.info.Gr, g.info.Gc)
         traj = [m.device_errors()]
         ref = log = None
         if tag != "fixed":
