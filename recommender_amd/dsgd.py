@@ -112,16 +112,108 @@ def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4):
     return ubp, ibp
 
 
+def pipeline_fits(n_items, ibp, rows, k, hot_buffers=8):
+    """Hot segments in a rank's shard grids: only where the free-block launch will walk them with the hot-item
+    pipeline (SGDRecommender.ExplicitMF._pipeline_runs: fp32, k = 64 / 128, stripe plus two row buffers within
+    a CU's LDS; a shard never has more non-empty stripes than the chooser's 256, so one workgroup runs per CU)."""
+    from .SGDRecommender import lds_bytes
+    return (k in (64, 128) and hot_buffers > 0
+            and lds_bytes(ibp, rows, k, 4, min(2, hot_buffers)) <= 160 * 1024)
+
+
+class RankWorker:
+    """One rank of the DSGD ring on its GPU.  It holds ONLY its own user super-stripe: the stripe's ratings (user
+    ids made local), one block grid per item shard built from them, and P / b_u rows for those users alone.  Q and
+    b_i are allocated whole (they are small next to P and the ring moves shards in place); only the shard the rank
+    currently holds is current."""
+
+    def __init__(self, plan, rank, train_local, k, b, hp, seed=0, hot_buffers=8, n_workgroups=0, waves_per_wg=0,
+                 test_local=None, log_blocks=False):
+        import torch
+        from . import _abi
+        from .SGDRecommender import Grid
+        _abi.require_gpu()
+        self.plan, self.rank, self.k, self.b, self.hp = plan, rank, k, float(b), hp
+        self.seed, self.n_workgroups, self.waves_per_wg = seed, n_workgroups, waves_per_wg
+        u0, u1 = plan.user_range(rank)
+        self.u0, self.nu = u0, u1 - u0
+        loc = train_local.clone()
+        if loc.shape[0]:
+            assert int(loc[:, 0].min()) >= u0 and int(loc[:, 0].max()) < u1, "train_local holds another rank's users"
+        loc[:, 0] -= u0
+        self.train = loc
+        self.test = None
+        if test_local is not None:
+            self.test = test_local.clone()
+            self.test[:, 0] -= u0
+        rows = max(1, -(-self.nu // plan.ubp))
+        hot = 32 if pipeline_fits(plan.n_items, plan.ibp, rows, k, hot_buffers) else 0
+        self.grids = []
+        for q in range(plan.world):
+            i0, i1 = plan.item_range(q)
+            sel = (loc[:, 1] >= i0) & (loc[:, 1] < i1)
+            g = Grid(loc[sel].contiguous(), max(1, self.nu), plan.n_items, plan.ubp, plan.ibp, order=1, hot_segments=hot)
+            if hot_buffers != 8:
+                g.set_hot_buffers(hot_buffers)
+            self.grids.append(g)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(int(seed) + 7919 * (rank + 1))          # this rank's users
+        self.P = torch.randn(max(1, self.nu), k, device="cuda", generator=gen) / k
+        self.b_u = torch.zeros(max(1, self.nu), device="cuda")
+        gen.manual_seed(int(seed))                              # the items: the same draw on every rank
+        self.Q = torch.randn(plan.n_items, k, device="cuda", generator=gen) / k
+        self.b_i = torch.zeros(plan.n_items, device="cuda")
+        self.logs = [] if log_blocks else None                  # (shard, int32 [Gr*Gc][2] device tensor) per compute()
+        self._calls = 0
+
+    def compute(self, q):
+        """One sub-epoch: the free-block epoch kernel on super-block (rank, q)."""
+        import torch
+        from . import _abi
+        g = self.grids[q]
+        log = None
+        if self.logs is not None:
+            log = torch.full((g.info.Gr * g.info.Gc, 2), -1, dtype=torch.int32, device="cuda")
+            self.logs.append((q, log))
+        a, b1, b2 = self.hp
+        _abi.check(_abi.lib().mfsgd_hip_epoch_f32(g.handle, self.k, _abi.ptr(self.P), _abi.ptr(self.Q), _abi.ptr(self.b_u),
+                                                  _abi.ptr(self.b_i), self.b, None, a, b1, b2, 0, 0, 1, 1,
+                                                  int(self.seed) + self._calls, self.n_workgroups, self.waves_per_wg,
+                                                  _abi.ptr(log), _abi.stream_ptr()))
+        self._calls += 1
+
+    def epoch(self, dist):
+        ring_epoch(self.plan, self.rank, self.Q, self.b_i, self.compute, dist)
+
+    def status(self):
+        for g in self.grids:
+            g.status()
+
+    def errors(self, dist):
+        """(train RMSE, held-out RMSE) of the whole job: shard owners broadcast, local sums, one all-reduce."""
+        import torch
+        from .numba_methods import rmse_exact
+        gather_items(self.plan, self.rank, self.Q, self.b_i, dist)
+        acc = torch.zeros(4, dtype=torch.float64, device="cuda")
+        for j, s in enumerate((self.train, self.test)):
+            if s is not None and s.shape[0]:
+                r = rmse_exact(s, None, None, self.P, self.Q, self.b_u, self.b_i, self.b)
+                acc[2 * j] = r * r * s.shape[0]
+                acc[2 * j + 1] = s.shape[0]
+        staged = dist.get_backend() == "gloo"
+        red = acc.cpu() if staged else acc
+        dist.all_reduce(red)
+        return float((red[0] / red[1]).sqrt()), float((red[2] / red[3].clamp(min=1)).sqrt())
+
+
 def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     """bench.py's multi-GPU leg (strong scaling: the same data set on 1..N GPUs)."""
     import json
     import torch
     import torch.distributed as dist
     from . import _abi
-    from .SGDRecommender import Grid, balanced_permutation
-    from .numba_methods import rmse_exact
+    from .SGDRecommender import balanced_permutation
 
-    alpha, beta1, beta2 = hp
     train, test, U, I, k = data
     n_train_total = int(train.shape[0])
     if args.grid:
@@ -130,7 +222,9 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     else:
         ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k)
     t0 = time.perf_counter()
-    # the same load-balancing permutation on every rank (identical inputs, deterministic algorithm)
+    # The bench generates the SAME synthetic data set on every rank (so that 1, 2, 4 and 8 GPUs train on identical
+    # ratings) and computes the same load-balancing permutation everywhere; from here on a rank keeps only its own
+    # users' ratings, P rows and biases (RankWorker).  A real job hands each rank its stripe and nothing else.
     du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
     di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
     rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
@@ -140,73 +234,47 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
         _abi.check(lib.mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), 3, _abi.ptr(rp), _abi.ptr(cp), U, I, _abi.stream_ptr()))
     plan = DSGDPlan(U, I, world, ubp, ibp)
     u0, u1 = plan.user_range(rank)
-    mine = (train[:, 0] >= u0) & (train[:, 0] < u1)
-    train_l = train[mine].contiguous()
-    tm = (test[:, 0] >= u0) & (test[:, 0] < u1)
-    test_l = test[tm].contiguous()
     b = float(train[:, 2].double().mean().item())
-    del train, test, mine, tm
-    grids = []
-    for q in range(world):
-        i0, i1 = plan.item_range(q)
-        sel = (train_l[:, 1] >= i0) & (train_l[:, 1] < i1)
-        grids.append(Grid(train_l[sel].contiguous(), U, I, ubp, ibp, order=1))
-        if args.hot_buffers != 8:
-            grids[-1].set_hot_buffers(args.hot_buffers)
+    train_l = train[(train[:, 0] >= u0) & (train[:, 0] < u1)].contiguous()
+    test_l = test[(test[:, 0] >= u0) & (test[:, 0] < u1)].contiguous()
+    del train, test, rp, cp
+    data = None
+    torch.cuda.empty_cache()
+    w = RankWorker(plan, rank, train_l, k, b, hp, seed=args.seed, hot_buffers=args.hot_buffers, n_workgroups=args.wgs,
+                   waves_per_wg=args.waves, test_local=test_l)
+    del train_l, test_l
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t0
-    g = torch.Generator(device="cuda")
-    g.manual_seed(args.seed)
-    P = torch.randn(U, k, device="cuda", generator=g) / k
-    Q = torch.randn(I, k, device="cuda", generator=g) / k
-    b_u = torch.zeros(U, device="cuda")
-    b_i = torch.zeros(I, device="cuda")
-
-    def compute(q):
-        _abi.check(lib.mfsgd_hip_epoch_f32(grids[q].handle, k, _abi.ptr(P), _abi.ptr(Q), _abi.ptr(b_u), _abi.ptr(b_i),
-                                           b, None, alpha, beta1, beta2, 0, 0, 1, 1, args.seed + q, args.wgs,
-                                           args.waves, None, _abi.stream_ptr()))
-
-    def errors():
-        gather_items(plan, rank, Q, b_i, dist)
-        acc = torch.zeros(4, dtype=torch.float64, device="cuda")
-        for j, s in enumerate((train_l, test_l)):
-            if s.shape[0]:
-                r = rmse_exact(s, None, None, P, Q, b_u, b_i, b)
-                acc[2 * j] = r * r * s.shape[0]
-                acc[2 * j + 1] = s.shape[0]
-        dist.all_reduce(acc)
-        return float((acc[0] / acc[1]).sqrt()), float((acc[2] / acc[3]).sqrt())
-
-    rm0 = errors()                               # before any training (the warm-up epochs train too)
+    rm0 = w.errors(dist)                         # before any training (the warm-up epochs train too)
     for _ in range(args.warmup):
-        ring_epoch(plan, rank, Q, b_i, compute, dist)
-    for gr in grids:
-        gr.status()
+        w.epoch(dist)
+    w.status()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ring_epoch(plan, rank, Q, b_i, compute, dist)
+        w.epoch(dist)
     torch.cuda.synchronize()
     dist.barrier()
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if dist.get_backend() == "gloo":
+        wall = wall.cpu()
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall = float(wall.item())
-    for gr in grids:
-        gr.status()
-    rm1 = errors()
+    w.status()
+    rm1 = w.errors(dist)
     if rank == 0:
         value = args.steps * n_train_total / wall
         Bk = bytes_per_update(k, "none")
+        gi = w.grids[0].info
         out = {
             "metric": "rating-updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape {U}x{I}, {n_train_total} train ratings, k={k}, implicit=none, "
-                                   f"DSGD ring over {world} GPUs, grid {plan.Gr}x{plan.Gc}, balanced renumbering"
-                                   + ", sequential inside a block",
-                       "hot_buffers": args.hot_buffers,
+                                   f"DSGD ring over {world} GPUs, grid {plan.Gr}x{plan.Gc} ({gi.Gr} user stripes per "
+                                   f"rank), balanced renumbering, sequential inside a block",
+                       "hot_buffers": args.hot_buffers, "hot_segment_ratings_rank0": int(sum(g.info.n_hot for g in w.grids)),
                        "n_train": n_train_total, "k": k, "grid": [plan.Gr, plan.Gc], "prep_seconds": prep_s},
             "roofline": {"bound": "hbm", "achieved": Bk * value / world / 1e9, "peak": hbm_peak / 1e9, "unit": "GB/s",
                          "frac": Bk * value / world / hbm_peak, "traffic": None, "bytes_per_update": Bk,
