@@ -83,7 +83,9 @@ def run_leg(args, torch, ra, data, k, hot_buffers):
     train, test, U, I = data
     m = ra.ExplicitMF(n_threads=15, n_factors=k, alpha=ALPHA, beta1=BETA1, beta2=BETA2, implicit=args.implicit,
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
-                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers, verbose=False)
+                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers,
+                      **({} if args.hot_items < 0 else {"hot_items": args.hot_items}),
+                      **({} if args.hot_cost < 0 else {"hot_cost": args.hot_cost}), verbose=False)
     m.load_samples_from_device(train.clone(), test.clone(), U, I)      # renumbering rewrites the ids in place
     np.random.seed(args.seed % (2 ** 31))
     t0 = time.perf_counter()
@@ -132,6 +134,10 @@ def main():
     ap.add_argument("--with-tickets-leg", action="store_true",
                     help="also time the same grid with the hot segments on the ticket path (hot_buffers 0)")
     ap.add_argument("--seed", type=int, default=BASE_SEED)
+    ap.add_argument("--hot-cost", type=float, default=-1.0,
+                    help="cost of a pipeline rating against a ticket-path one when the items are dealt to stripes")
+    ap.add_argument("--hot-items", type=int, default=-1,
+                    help="hot items (hot segments per block) a stripe may have where the pipeline runs (default: the library's)")
     ap.add_argument("--hot-buffers", type=int, default=8,
                     help="LDS row buffers of the hot-item pipeline (mfsgd_grid_set_hot_buffers); 0 = every rating "
                          "through the item tickets.  Either way a block is walked sequentially in stored order")

@@ -135,6 +135,7 @@ int mfsgd_hip_topn_f32(const float *P, const float *Q, const float *b_u, const f
  * ratings with per-item tickets, so that a workgroup can walk one block with many waves and still
  * produce exactly the block's sequential result. */
 typedef struct mfsgd_grid mfsgd_grid;
+#define MFSGD_MAX_HOT 8   /* hot items (hot segments per block) an item stripe may have */
 
 typedef struct {
     int64_t n, n_runs, n_users, n_items;
@@ -143,26 +144,31 @@ typedef struct {
     int32_t user_unique;  /* 1 if no user has two runs in one segment of a block (always for order 1) */
     int64_t max_block, max_col_nnz, max_row_nnz;
     int64_t n_hot;         /* ratings stored in hot segments (order 1; 0 otherwise) */
-    int32_t n_hot_stripes; /* item stripes with a hot item: their most rated item carries >= 1/16 of the stripe's ratings */
-    int32_t reserved;
+    int32_t n_hot_stripes; /* item stripes with at least one hot item */
+    int32_t n_hot_items;   /* hot items over all stripes (<= MFSGD_MAX_HOT per stripe) */
 } mfsgd_grid_info;
 
 /* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);
- * order 1 (throughput mode): inside a block first the ratings of the stripe's hot item, one run per user (the hot
- *          segment, see mfsgd_grid_set_hot_buffers), then all other ratings sorted by user (one run per user),
- *          ties in input order.  If a (user, hot item) pair occurs twice the grid is built without hot segments. */
+ * order 1 (throughput mode): inside a block first the ratings of the stripe's hot item(s), one run per user (the hot
+ *          segments, see mfsgd_grid_set_hot_buffers and mfsgd_grid_create_opt), then all other ratings sorted by
+ *          user (one run per user), ties in input order.  If a (user, hot item) pair occurs twice the grid is built
+ *          without hot segments. */
 int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                       int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
-/* The same with the hot segments at the caller's choice: a stripe's most rated item becomes its hot item only if it
- * also has, on average, at least hot_min_per_block ratings per block of the stripe (degree >= hot_min_per_block * Gr);
- * 0 = no hot segments at all (every block of an order-1 grid sorted by user only).  Hot segments pay when the
- * hot-item pipeline walks them (mfsgd_grid_set_hot_buffers) in batches of 32, and cost time when they go through
- * the item tickets (a block then starts with a stretch in which every wave waits for the same item), so a caller
- * that knows the pipeline will not run - k other than 64 / 128, fp64, an implicit term, item stripes that leave no
- * LDS for its row buffers - passes 0, and one that knows it will passes 32.  mfsgd_grid_create is 1 (any length). */
+/* The same with the hot segments at the caller's choice: up to hot_items (0 .. MFSGD_MAX_HOT) of a stripe's most rated
+ * items become its hot items - item s's ratings form hot segment s in front of every block of the stripe, one
+ * single-rating run per user, by user - each with at least 256 ratings and, on average, at least hot_min_per_block
+ * ratings per block of the stripe (degree >= hot_min_per_block * Gr); hot_items = 0: no hot segments at all (every
+ * block of an order-1 grid sorted by user only).  A rating that goes through the hot-item pipeline
+ * (mfsgd_grid_set_hot_buffers) costs about a third of one that goes through the item tickets (netflix shape, k = 128),
+ * in batches of 32; hot segments that go through the tickets cost time (a block then starts with a stretch in
+ * which every wave waits for the same item).  So a caller that knows the pipeline will run passes (MFSGD_MAX_HOT, 32),
+ * and one that knows it will not - k other than 64 / 128 / 256, fp64, an implicit term, item stripes that leave no
+ * LDS for its row buffers - passes (0, 0).  mfsgd_grid_create is one hot item per stripe of any length, if it
+ * carries >= 1/16 of the stripe's ratings. */
 int mfsgd_grid_create_opt(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
-                          int32_t ubp, int32_t ibp, int32_t order, int32_t hot_min_per_block, void *stream,
-                          mfsgd_grid **out);
+                          int32_t ubp, int32_t ibp, int32_t order, int32_t hot_items, int32_t hot_min_per_block,
+                          void *stream, mfsgd_grid **out);
 int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info);
 void mfsgd_grid_destroy(mfsgd_grid *g);
 /* Copies the grid's arrays into caller buffers (any may be NULL): blk_run_ptr[Gr*Gc+1], run_start[n_runs+1],
@@ -187,8 +193,8 @@ int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n);
  * only); -1 on bad arguments.  A CU has 160 KB.  Touches no device.  No counterpart in the reference (its grid is
  * (n_threads+1)^2, SGDRecommender.py:189-192). */
 int64_t mfsgd_lds_bytes(int32_t ibp, int32_t Gr, int32_t k, int32_t elem_size, int32_t hot_bufs);
-/* h_col_hot[Gc] (HOST): for every item stripe the global id of the item mfsgd_grid_set_hot_batch applies to,
- * or -1.  Synchronises. */
+/* h_col_hot[Gc][MFSGD_MAX_HOT] (HOST): for every item stripe the global ids of its hot items, most rated first;
+ * -1 = none.  Synchronises. */
 int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream);
 /* Synchronises and reports whether an epoch kernel ran out of patience on a wait (every spin in the
  * kernels is bounded); clears the flag. */

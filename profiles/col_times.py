@@ -27,6 +27,8 @@ ok = en > 0
 t_first = st[ok].min()
 dur = (en - st) / 100.0          # us
 hot = g.col_hot()
+n_hot_items = (hot >= 0).sum(1)
+hot = hot[:, 0]
 deg = torch.bincount(m._d_samples[:, 1].long(), minlength=I).cpu().numpy()
 print(f"hot_buffers {m.hot_buffers}, stripes with a hot item {g.info.n_hot_stripes} ({int(g.info.n_hot)} ratings), top item degrees {np.sort(deg)[-5:][::-1].tolist()}")
 print(f"epoch {dt*1e3:.1f} ms, grid {g.info.Gr}x{g.info.Gc}, runs {g.info.n_runs}, n {g.info.n}, avg run {g.info.n/g.info.n_runs:.2f}")
@@ -34,6 +36,6 @@ print("tenure us: min %.0f med %.0f max %.0f ; end-of-last %.0f us ; start-of-la
 order = np.argsort(-nnz)
 slow = np.argsort(-dur)
 for c in list(slow[:6]) + list(order[:3]) + list(order[len(order)//2:len(order)//2+3]) + list(order[-3:]):
-    print(f"col {c}: hot item deg {deg[hot[c]] if hot[c] >= 0 else 0} nnz {nnz[c]} start {(st[c]-t_first)/100:.0f} us dur {dur[c]:.0f} us -> {nnz[c]/max(dur[c],1):.2f} ratings/us")
+    print(f"col {c}: {n_hot_items[c]} hot items, top deg {deg[hot[c]] if hot[c] >= 0 else 0} nnz {nnz[c]} start {(st[c]-t_first)/100:.0f} us dur {dur[c]:.0f} us -> {nnz[c]/max(dur[c],1):.2f} ratings/us")
 rate = nnz[ok] / np.maximum(dur[ok], 1)
 print("ratings/us per tenure: min %.2f med %.2f max %.2f" % (rate.min(), np.median(rate), rate.max()))

@@ -33,12 +33,15 @@ from .SubSample import SubSample
 _IMPLICIT = {"none": 0, "frozen": 1, "full": 2}
 
 
-def balanced_permutation(deg, width):
+def balanced_permutation(deg, width, cost=None):
     """new_id[old_id] such that the stripes [s*width, (s+1)*width) of the new numbering carry near-equal
-    sums of `deg`: ids by decreasing degree, each to the least-loaded stripe that still has a free slot."""
+    sums of `cost` (default: `deg`): ids by decreasing degree, each to the least-loaded stripe that still has a
+    free slot."""
     import heapq
     deg = np.asarray(deg)
     N = len(deg)
+    if cost is not None:
+        return _balanced_by_cost(deg, np.asarray(cost, dtype=np.float64), width)
     G = -(-N // width)
     cap = [width] * (G - 1) + [N - (G - 1) * width]
     order = np.argsort(-deg, kind="stable")
@@ -71,12 +74,34 @@ def balanced_permutation(deg, width):
     return new_id
 
 
+def _balanced_by_cost(deg, cost, width):
+    import heapq
+    N = len(deg)
+    G = -(-N // width)
+    cap = [width] * (G - 1) + [N - (G - 1) * width]
+    order = np.argsort(-deg, kind="stable")
+    new_id = np.empty(N, dtype=np.int64)
+    heap = [(0.0, s) for s in range(G)]
+    used = [0] * G
+    for old, c in zip(order.tolist(), cost[order].tolist()):
+        load, s = heapq.heappop(heap)
+        new_id[old] = s * width + used[s]
+        used[s] += 1
+        if used[s] < cap[s]:
+            heapq.heappush(heap, (load + c, s))
+    return new_id
+
+
+HOT_RATING_COST = 0.35      # a rating on the hot-item pipeline against one on the ticket path (netflix shape, k = 128:
+                            # per-stripe tenure times fitted as 0.094 us * rest + 0.031 us * hot, profiles/r2_col_times.txt)
+
+
 def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
     """LDS a free-block workgroup needs for item stripes of `ibp` items (lds_plan in csrc/epoch.hip, kept in
     step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes); `hot_bufs` row buffers of the hot-item
     pipeline (float32 only, 32 rows of k + 4 floats each) on top."""
     up = lambda x: (x + 15) & ~15
-    o = up((16 + 128) * 4)
+    o = up((16 + 128 + 5 * _abi.MAX_HOT + 4) * 4)
     o = up(o + ibp * 4)
     o = up(o + Gr)
     o = up(o + Gr * 12)
@@ -92,14 +117,22 @@ def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
 class Grid:
     """Owner of a device block grid (mfsgd_grid_*)."""
 
-    def __init__(self, d_samples, n_users, n_items, ubp, ibp, order, hot_segments=1):
-        """hot_segments: 0 / False = none; N > 0 = a stripe's most rated item needs >= N ratings per block on average
-        (mfsgd_grid_create_opt); 1 / True = the rule of mfsgd_grid_create."""
+    def __init__(self, d_samples, n_users, n_items, ubp, ibp, order, hot_segments=None):
+        """hot_segments: None = the rule of mfsgd_grid_create (one hot item per stripe when it carries 1/16 of it);
+        0 / False = none; (items, min_per_block) = mfsgd_grid_create_opt: up to `items` hot items per stripe, each
+        with at least `min_per_block` ratings per block on average."""
         _abi.require_gpu()
         h = _abi.c_vp(0)
-        _abi.check(_abi.lib().mfsgd_grid_create_opt(_abi.ptr(d_samples), int(d_samples.shape[0]), int(d_samples.shape[1]),
+        if hot_segments is None:
+            _abi.check(_abi.lib().mfsgd_grid_create(_abi.ptr(d_samples), int(d_samples.shape[0]), int(d_samples.shape[1]),
                                                     int(n_users), int(n_items), int(ubp), int(ibp), int(order),
-                                                    int(hot_segments), _abi.stream_ptr(), _abi.C.byref(h)))
+                                                    _abi.stream_ptr(), _abi.C.byref(h)))
+        else:
+            items, per_block = hot_segments if hot_segments else (0, 0)
+            _abi.check(_abi.lib().mfsgd_grid_create_opt(_abi.ptr(d_samples), int(d_samples.shape[0]),
+                                                        int(d_samples.shape[1]), int(n_users), int(n_items), int(ubp),
+                                                        int(ibp), int(order), int(items), int(per_block),
+                                                        _abi.stream_ptr(), _abi.C.byref(h)))
         self.handle = h
         info = _abi.GridInfo()
         _abi.check(_abi.lib().mfsgd_grid_get_info(self.handle, _abi.C.byref(info)))
@@ -115,8 +148,9 @@ class Grid:
         _abi.check(_abi.lib().mfsgd_grid_set_hot_buffers(self.handle, int(n)))
 
     def col_hot(self):
-        """Per item stripe: global id of the stripe's hot item (its ratings form the blocks' hot segments), or -1."""
-        out = np.full(self.info.Gc, -1, dtype=np.int32)
+        """[Gc][MFSGD_MAX_HOT]: per item stripe the global ids of its hot items, most rated first (item s's ratings form
+        hot segment s of the stripe's blocks); -1 = none."""
+        out = np.full((self.info.Gc, _abi.MAX_HOT), -1, dtype=np.int32)
         _abi.check(_abi.lib().mfsgd_grid_col_hot(self.handle, out.ctypes.data_as(_abi.c_vp), _abi.stream_ptr()))
         return out
 
@@ -165,6 +199,8 @@ class ExplicitMF(Recommender):
                  grid=None,              # (Gr, Gc) of the throughput grid; None = chosen from the shapes
                  exact_errors=True,      # geterrors over all rows (the reference subsamples, mse2)
                  hot_buffers=None,       # LDS row buffers of the hot-item pipeline (None = 8, as many as fit; 0 = ticket path only)
+                 hot_items=1,            # hot items (hot segments per block) a stripe may have where the pipeline runs (<= 8)
+                 hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -180,6 +216,8 @@ class ExplicitMF(Recommender):
         self.grid_shape = grid
         self.exact_errors = exact_errors
         self.hot_buffers = 8 if hot_buffers is None else int(hot_buffers)
+        self.hot_items = int(hot_items)
+        self.hot_cost = hot_cost
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -265,19 +303,21 @@ class ExplicitMF(Recommender):
 
     # ------------------------------------------------------------------ the GPU FPSGD path
     def _pipeline_kernel(self):
-        """The hot-item pipeline exists for fp32, k = 64 or 128, no implicit term (csrc/epoch.hip, FASTA)."""
+        """The hot-item pipeline is worth its hot segments for fp32, k = 64 or 128, no implicit term.  The kernel also
+        exists for k = 256 (csrc/epoch.hip, FASTA; parity-tested), but a batch's row buffer is 33 KB there, two fit
+        next to a stripe, and two pipeline waves are slower than the tickets (netflix shape, k = 256: 74 ms per epoch
+        against 56 ms), so the chooser does not ask for hot segments at k = 256."""
         return (self.dtype != "float64" and self.n_factors in (64, 128) and (self.implicit or "frozen") == "none"
                 and self.hot_buffers > 0)
 
     def _pipeline_runs(self, Gr, Gc):
         """Will the free-block launch walk hot segments with the pipeline on a Gr x Gc grid?  It does when the kernel
-        exists, one workgroup runs per CU (launch_epochs: two share a CU when there are more stripes than CUs and two
-        stripes fit its LDS) and at least two of its row buffers fit behind the stripe (one wave alone is no pipeline)."""
+        exists and at least two of its row buffers fit behind the stripe in a CU's LDS (one wave alone is no pipeline);
+        the launch then runs one workgroup per CU on the 128-register build (launch_epochs)."""
         if not self._pipeline_kernel():
             return False
         ibp = -(-self.n_items // Gc)
-        two_per_cu = Gc > 256 and 2 * lds_bytes(ibp, Gr, self.n_factors, 4) <= 160 * 1024
-        return not two_per_cu and lds_bytes(ibp, Gr, self.n_factors, 4, min(2, self.hot_buffers)) <= 160 * 1024
+        return lds_bytes(ibp, Gr, self.n_factors, 4, min(2, self.hot_buffers)) <= 160 * 1024
 
     def _choose_grid(self):
         """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table) in LDS, and a CU has
@@ -326,10 +366,11 @@ class ExplicitMF(Recommender):
         else:
             ubp, ibp = self._choose_grid()
             # hot segments only where the pipeline will walk them: through the item tickets they cost time
-            # (ML-25M shape, 288 x 256: 11.8 ms per epoch without them, 13.0 ms with)
-            # and only segments of at least one pipeline batch (32 ratings) per block on average (ML-1M shape, blocks
-            # of ~130 ratings: 1.26 ms per epoch without hot segments, 1.70 ms with)
-            hot = 32 if self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp)) else 0
+            # (ML-25M shape, 288 x 256: 11.8 ms per epoch without them, 13.0 ms with); and only items that fill at least
+            # one pipeline batch (32 ratings) per block on average (ML-1M shape, blocks of ~130 ratings: 1.26 ms per
+            # epoch without hot segments, 1.70 ms with)
+            runs = self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp))
+            hot = (self.hot_items, 32) if runs and self.hot_items > 0 else 0
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)
         if self.hot_buffers != 8:
             self._grid.set_hot_buffers(self.hot_buffers)
@@ -496,7 +537,16 @@ class ExplicitMF(Recommender):
         ubp, ibp = self._choose_grid()
         du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
         di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
-        self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp))
+        Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
+        cost = None
+        if self._pipeline_runs(Gr, Gc) and self.hot_items > 0 and self.n_items <= (1 << 21):
+            # the stripes' hot items - the hot_items * Gc most rated ones, as far as they qualify (build_grid) - go
+            # through the pipeline, where a rating costs about a third: balance time, not counts
+            cost = di.astype(np.float64)
+            top = np.argsort(-di, kind="stable")[:self.hot_items * Gc]
+            top = top[di[top] >= max(256, 32 * Gr)]
+            cost[top] *= HOT_RATING_COST if self.hot_cost is None else float(self.hot_cost)
+        self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):
         """Remap ids by `row_index` / `col_index` (current id -> new id).  self.row_perm / col_perm always map the

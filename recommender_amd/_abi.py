@@ -5,6 +5,8 @@ kernel behind the C-ABI.  There is NO CPU fallback: without the library or witho
 entry point raises.
 """
 import ctypes as C
+
+MAX_HOT = 8          # MFSGD_MAX_HOT (include/mfsgd.h): hot items an item stripe may have
 import os
 
 import numpy as np
@@ -22,7 +24,7 @@ class GridInfo(C.Structure):
                 ("Gr", c_i32), ("Gc", c_i32), ("ubp", c_i32), ("ibp", c_i32),
                 ("order", c_i32), ("user_unique", c_i32),
                 ("max_block", c_i64), ("max_col_nnz", c_i64), ("max_row_nnz", c_i64),
-                ("n_hot", c_i64), ("n_hot_stripes", c_i32), ("reserved", c_i32)]
+                ("n_hot", c_i64), ("n_hot_stripes", c_i32), ("n_hot_items", c_i32)]
 
 
 def _sig_sgd(ct):
@@ -63,7 +65,7 @@ SIGNATURES = {
     "mfsgd_hip_als_step_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "mfsgd_hip_als_step_f64": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f64, c_vp]),
     "mfsgd_grid_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
-    "mfsgd_grid_create_opt": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
+    "mfsgd_grid_create_opt": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp)]),
     "mfsgd_grid_get_info": (C.c_int, [c_vp, C.POINTER(GridInfo)]),
     "mfsgd_grid_destroy": (None, [c_vp]),
     "mfsgd_grid_export": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -45,13 +45,16 @@ struct DevBuf {
 using mfprep::DevBuf;
 
 constexpr int PA_MAX_BUFS_DEFAULT = 8;
+constexpr int MAXSEG = MFSGD_MAX_HOT;   // hot segments per block
+constexpr int NCLS = MAXSEG + 1;         // classes of a rating inside its block: hot segment 0 .. MAXSEG-1, the rest
 struct mfsgd_grid {
     mfsgd_grid_info info{};
     int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
     float *val = nullptr;
     int32_t *col_order = nullptr;  // item stripes, heaviest first
-    int32_t *col_hot = nullptr;      // [Gc] the stripe's hot item (global id): its ratings form the hot segment of every block of the stripe; -1: none
-    int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] length of the block's hot segment (ratings of that item, one per user)
+    int32_t *col_hot = nullptr;      // [Gc][MAXSEG] the stripe's hot items (global ids, most rated first; -1: none): item s forms hot segment s of every block of the stripe
+    int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings in the block's hot segments (all of them together)
+    int32_t *blk_seg_cnt = nullptr;  // [Gr*Gc][MAXSEG] length of each hot segment (ratings of that item, one per user)
     int32_t max_block_runs = 0;
     int32_t hot_bufs = PA_MAX_BUFS_DEFAULT;   // LDS row buffers the hot-item pipeline may take (0: ticket path only)
     int32_t *row_lock = nullptr;   // [Gr]
@@ -71,7 +74,7 @@ struct GridView {
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
-    const int32_t *col_hot, *blk_hot_cnt;   // [Gc] the stripe's hot item or -1; [Gr*Gc] length of the block's hot segment
+    const int32_t *col_hot, *blk_hot_cnt, *blk_seg_cnt;   // see mfsgd_grid
 };
 
 struct SchedView {
@@ -124,15 +127,15 @@ __global__ void k_gather_soa(const int32_t *__restrict__ s, int32_t stride, cons
     val[t] = (float)s[o * stride + 2];
 }
 
-// a run = a maximal stretch of one user's ratings inside a block; in the hot segment (hot != nullptr) every rating
-// is a run of its own and the segment's end is a run boundary even if the same user follows
+// a run = a maximal stretch of one user's ratings inside a block; in a hot segment (cls != nullptr, class < MAXSEG)
+// every rating is a run of its own, and a change of class is a run boundary even if the same user follows
 __global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user,
-                            const uint8_t *__restrict__ hot, int64_t n, int32_t *flag)
+                            const uint8_t *__restrict__ cls, int64_t n, int32_t *flag)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     bool f = t == 0 || bkey[t] != bkey[t - 1] || user[t] != user[t - 1];
-    if (hot && t > 0) f = f || hot[t] || hot[t - 1];
+    if (cls && t > 0) f = f || cls[t] < MAXSEG || cls[t] != cls[t - 1];
     flag[t] = f ? 1 : 0;
 }
 
@@ -142,33 +145,42 @@ __global__ void k_item_deg_raw(const int32_t *__restrict__ s, int64_t n, int32_t
     if (t < n) atomicAdd(&deg[s[t * stride + 1]], 1);
 }
 
-// order 1 sorts a block's ratings of the stripe's hot item in front of the others: key = 2 * block + (hot ? 0 : 1)
+// order 1 sorts a block's ratings of the stripe's hot items in front of the others, one segment per item:
+// key = NCLS * block + class, class = s for hot item s of the stripe, MAXSEG for every other item
 __global__ void k_hot_block_key(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t Gc,
                                 const int32_t *__restrict__ col_hot, uint32_t *bkey)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t b = bkey[t];
-    bkey[t] = 2 * b + (s[t * stride + 1] == col_hot[b % (uint32_t)Gc] ? 0u : 1u);
+    const int32_t item = s[t * stride + 1];
+    const int32_t *h = col_hot + (size_t)(b % (uint32_t)Gc) * MAXSEG;
+    uint32_t c = MAXSEG;
+#pragma unroll
+    for (int j = 0; j < MAXSEG; ++j)
+        if (h[j] == item) c = j;
+    bkey[t] = NCLS * b + c;
 }
 
-__global__ void k_split_hot_key(uint32_t *bkey, int64_t n, uint8_t *hot)
+__global__ void k_split_hot_key(uint32_t *bkey, int64_t n, uint8_t *cls)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t b = bkey[t];
-    hot[t] = (b & 1u) ? 0 : 1;
-    bkey[t] = b >> 1;
+    cls[t] = (uint8_t)(b % NCLS);
+    bkey[t] = b / NCLS;
 }
 
-// hot segment: blk_hot_cnt[block] = its length; *dup = 1 if a user occurs twice in one (a duplicate (user, item) pair)
+// hot segments: blk_seg_cnt[block][s] = length of segment s, blk_hot_cnt[block] = their sum; *dup = 1 if a user
+// occurs twice in one segment (a duplicate (user, item) pair)
 __global__ void k_hot_count(const uint32_t *__restrict__ bkey, const int32_t *__restrict__ user,
-                            const uint8_t *__restrict__ hot, int64_t n, int32_t *blk_hot_cnt, int32_t *dup)
+                            const uint8_t *__restrict__ cls, int64_t n, int32_t *blk_seg_cnt, int32_t *blk_hot_cnt, int32_t *dup)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n || !hot[t]) return;
+    if (t >= n || cls[t] >= MAXSEG) return;
+    atomicAdd(&blk_seg_cnt[(size_t)bkey[t] * MAXSEG + cls[t]], 1);
     atomicAdd(&blk_hot_cnt[bkey[t]], 1);
-    if (t > 0 && hot[t - 1] && bkey[t - 1] == bkey[t] && user[t - 1] == user[t]) *dup = 1;
+    if (t > 0 && cls[t - 1] == cls[t] && bkey[t - 1] == bkey[t] && user[t - 1] == user[t]) *dup = 1;
 }
 
 __global__ void k_run_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ excl,
@@ -243,26 +255,38 @@ inline int bits_for(uint64_t maxkey)
     return b;
 }
 
-// The most rated item of a stripe becomes the stripe's HOT item when it carries at least 1/HOT_SHARE_DIV of the
-// stripe's ratings, i.e. more than one wave's fair share - its chain of updates then bounds the stripe - and on
-// average at least `min_per_block` ratings per block of the stripe (the caller's choice, mfsgd_grid_create_opt): its
-// ratings are stored as the hot segment in front of every block (hot-item pipeline, phase_a_gram).  Segments shorter
-// than a pipeline batch cost more than the chain they remove (ML-1M shape, 93 x 75 blocks of ~130 ratings: 1.70 ms
-// per epoch with them, 1.26 ms without).
+// HOT items of a stripe: its most rated items, at most `max_hot` of them (most rated first, equal degrees by lower id),
+// each with at least HOT_MIN_DEG ratings and at least `min_deg` = min_per_block * Gr (on average min_per_block
+// ratings per block of the stripe, the caller's choice - mfsgd_grid_create_opt); with `need_share` an item must also
+// carry 1/HOT_SHARE_DIV of the stripe's ratings, i.e. more than one wave's fair share (the rule of mfsgd_grid_create).
+// Item s's ratings are stored as hot segment s in front of every block of the stripe (hot-item pipeline,
+// phase_a_gram).  Segments much shorter than a pipeline batch cost more than they save (ML-1M shape, 93 x 75 blocks of
+// ~130 ratings: 1.70 ms per epoch with them, 1.26 ms without).
 constexpr int HOT_SHARE_DIV = 16;
 constexpr int HOT_MIN_DEG = 256;
-__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int64_t min_deg, int32_t *col_hot)
+__global__ void k_col_hot(const int32_t *__restrict__ deg, int64_t n_items, int32_t ibp, int32_t Gc, int32_t max_hot,
+                          int64_t min_deg, int32_t need_share, int32_t *col_hot)
 {
     const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Gc) return;
     int64_t total = 0;
-    int32_t best = -1, best_deg = 0;
-    for (int64_t i = (int64_t)c * ibp; i < (int64_t)(c + 1) * ibp && i < n_items; ++i) {
-        total += deg[i];
-        if (deg[i] > best_deg) { best_deg = deg[i]; best = (int32_t)i; }
+    for (int64_t i = (int64_t)c * ibp; i < (int64_t)(c + 1) * ibp && i < n_items; ++i) total += deg[i];
+    int32_t last_deg = 0x7fffffff, last_id = -1;
+    bool open = true;
+    for (int s = 0; s < MAXSEG; ++s) {
+        int32_t best = -1, best_deg = 0;
+        if (open && s < max_hot)
+            for (int64_t i = (int64_t)c * ibp; i < (int64_t)(c + 1) * ibp && i < n_items; ++i) {
+                const int32_t d = deg[i];
+                const bool later = d < last_deg || (d == last_deg && (int32_t)i > last_id);   // not picked yet
+                if (later && d > best_deg) { best_deg = d; best = (int32_t)i; }
+            }
+        const bool hot = best >= 0 && best_deg >= HOT_MIN_DEG && (int64_t)best_deg >= min_deg &&
+                         (!need_share || (int64_t)best_deg * HOT_SHARE_DIV >= total);
+        col_hot[(size_t)c * MAXSEG + s] = hot ? best : -1;
+        if (!hot) open = false;   // degrees only fall from here on
+        last_deg = best_deg; last_id = best;
     }
-    const bool hot = best_deg >= HOT_MIN_DEG && (int64_t)best_deg * HOT_SHARE_DIV >= total && (int64_t)best_deg >= min_deg;
-    col_hot[c] = hot ? best : -1;
 }
 
 template <typename K, typename V>
@@ -310,8 +334,15 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_TAIL, PF_DRAIN, PF_BARRIER, PF_RUNS,
        PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 32 };
 
-constexpr int CTL_WORDS = 16 + 128;  // 16 control words + 128 sink words (see sink_ptr)
-enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_TOKEN = 4, CTL_FRONT = 5, CTL_FUSER = 6, CTL_SINK = 16 };
+constexpr int CTL_WORDS = 16 + 128 + 5 * MAXSEG + 4;  // 16 control words + 128 sink words (see sink_ptr) + the hot segments' words
+// hot-item pipeline, per hot segment s of the block in flight: CTL_TOKEN + s = batches whose chain is done (whose turn it
+// is), CTL_FRONT + s = batches published, CTL_FUSER + s = "segment s is done for every user <= this" (0x7fffffff: all)
+// CTL_BND + p, p = 0 .. MAXSEG + 1: run ranges of the block's passes (hot segments, then the rest; process_block)
+// CTL_FMIN: a lower bound of the minimum of all CTL_FUSER words, only ever raised (atomic max): what the rest of the
+// block waits behind
+enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_FMIN = 4, CTL_SINK = 16, CTL_TOKEN = 16 + 128,
+       CTL_FRONT = CTL_TOKEN + MAXSEG, CTL_FUSER = CTL_FRONT + MAXSEG, CTL_BND = CTL_FUSER + MAXSEG,
+       CTL_HOT = CTL_BND + MAXSEG + 2 };   // CTL_HOT + s: hot item s of the stripe in tenure (global id, -1: none)
 
 // "Only lane 0 does X" is written WITHOUT a branch everywhere in this file: every lane executes the store or
 // atomic, lane 0 on the real address and lane l>0 on its own sink word in LDS.  Reason (seen in the gfx950
@@ -631,27 +662,120 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 typedef float pa_f32x16 __attribute__((ext_vector_type(16)));
 typedef float pa_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KC>
-__device__ __forceinline__ void phase_a_gram(const int32_t *__restrict__ hu, const float *__restrict__ hv, int32_t nh,
-                                             float *__restrict__ P,
-                                             float *__restrict__ b_u, float b, float alpha, float beta1, float beta2,
-                                             int variant, float *qrow, float *bip, float *abuf, uint32_t abuf_floats,
-                                             int n_abuf, int *ctl, int32_t *err PF_PARAM)
+// min over the hot segments below `below` of "done for every user <= this" (empty segments hold 0x7fffffff)
+__device__ __forceinline__ int32_t hot_frontier(const int *ctl, int below)
 {
+    int32_t f = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+        const int32_t v = __hip_atomic_load(&ctl[CTL_FUSER + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (s < below && v < f) f = v;
+    }
+    return __builtin_amdgcn_readfirstlane(f);
+}
+
+// The hot segments of one block: segment s = ratings [t_lo + pre_s, t_lo + pre_s + cnt[s]) = single-rating runs
+// [run_lo + pre_s, ...), pre_s = cnt[0] + .. + cnt[s-1], all of item hot[s], in batches of 32.  A batch waits for (a) every
+// EARLIER segment to be done for its users (hot_frontier: a user's ratings are applied in stored order, segment after
+// segment) before it loads their rows, and (b) the previous batch of its own segment (the item's chain, CTL_TOKEN).
+// The pipeline waves are SPLIT among the segments, so that all segments move through the user range together and the
+// frontier the rest of the block waits behind advances steadily: with at least as many waves as non-empty segments
+// every segment gets one wave and the spare waves go where the most batches per wave are left (a segment's waves take
+// its batches round robin); with fewer waves, wave w takes the non-empty segments w, w + n_abuf, .. whole, in order.
+// Either way a wave only ever waits for LOWER segments or for an earlier batch of its own, and it takes its work in
+// increasing (segment, batch) order: whoever holds the earliest unfinished batch can always proceed.
+// MULTI = false: the stripe has ONE hot item (cnt[0] = the block's hot ratings, hot[0] = the item): no split, no look at
+// other segments - a second instantiation, because the bookkeeping of the general case costs scalar registers that
+// the single-item pipeline (the default) then spills (netflix shape: 32.2 ms per epoch against 30.4 ms).
+template <int KC, bool MULTI>
+__device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, int32_t t_lo, int32_t c_base,
+                                             float *__restrict__ P, float *__restrict__ b_u, float b, float alpha,
+                                             float beta1, float beta2, int variant, float *qs, float *bis, float *abuf,
+                                             uint32_t abuf_floats, int n_abuf, int *ctl, int32_t *err PF_PARAM)
+{
+    // segment lengths and hot items come from the control words (process_block, k_epoch_free wrote them before a
+    // barrier): kept in scalar registers across the run loop they were spilled
+    int32_t cnt[MAXSEG], hot[MAXSEG];
+#pragma unroll
+    for (int s = 0; s < (MULTI ? MAXSEG : 1); ++s) {
+        cnt[s] = __builtin_amdgcn_readfirstlane(ctl[CTL_BND + s + 1] - ctl[CTL_BND + s]);
+        hot[s] = __builtin_amdgcn_readfirstlane(ctl[CTL_HOT + s]);
+    }
     constexpr int K = 64 * KC, LD = K + 4;
     constexpr int LPR = K / 4, RPI = 64 / LPR;     // lanes per row and rows per 128-bit load instruction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= n_abuf) return;
     float *buf = abuf + (size_t)wave * abuf_floats;
     const int col = lane & 31, kh = lane >> 5;
-    const int32_t nbatch = (nh + PA_B - 1) / PA_B;
     const float a = 1.f - alpha * beta2;
-    for (int32_t m = wave; m < nbatch; m += n_abuf) {
+    // this wave's share: of segment s it takes batches first[s], first[s] + step[s], ..  (step 0: none)
+    int32_t first[MAXSEG], step[MAXSEG];
+    if constexpr (!MULTI) {
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s) { first[s] = wave; step[s] = s == 0 ? n_abuf : 0; }
+    } else {
+        int32_t nbat[MAXSEG], nwv[MAXSEG], nseg = 0;
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s) { nbat[s] = (cnt[s] + PA_B - 1) / PA_B; nwv[s] = nbat[s] > 0 ? 1 : 0; nseg += nwv[s]; }
+        if (nseg <= n_abuf) {
+            for (int extra = n_abuf - nseg; extra > 0; --extra) {   // spare waves: most batches per wave first
+                int best = -1;
+                int64_t bn = 0, bd = 1;
+#pragma unroll
+                for (int s = 0; s < MAXSEG; ++s)
+                    if (nwv[s] > 0 && nbat[s] > nwv[s] && (int64_t)nbat[s] * bd > bn * nwv[s]) { best = s; bn = nbat[s]; bd = nwv[s]; }
+                if (best < 0) break;
+#pragma unroll
+                for (int s = 0; s < MAXSEG; ++s)
+                    if (s == best) ++nwv[s];
+            }
+            int32_t before = 0;
+#pragma unroll
+            for (int s = 0; s < MAXSEG; ++s) {
+                const bool mine = wave >= before && wave < before + nwv[s];
+                first[s] = wave - before;
+                step[s] = mine ? nwv[s] : 0;
+                before += nwv[s];
+            }
+        } else {
+            int32_t j = 0;
+#pragma unroll
+            for (int s = 0; s < MAXSEG; ++s) {
+                const bool mine = nbat[s] > 0 && j % n_abuf == wave;
+                first[s] = 0;
+                step[s] = mine ? 1 : 0;
+                j += nbat[s] > 0 ? 1 : 0;
+            }
+        }
+    }
+    for (int32_t seg = 0; seg < (MULTI ? MAXSEG : 1); ++seg) {
+        int32_t nh = 0, hot_item = 0, pre = 0, m0 = 0, dm = 0;
+#pragma unroll
+        for (int s = 0; s < (MULTI ? MAXSEG : 1); ++s) {
+            if (s == seg) { nh = cnt[s]; hot_item = hot[s]; m0 = first[s]; dm = step[s]; }
+            if (s < seg) pre += cnt[s];
+        }
+        if (dm == 0) continue;
+        const int32_t nbatch = (nh + PA_B - 1) / PA_B;
+    for (int32_t m = m0; m < nbatch; m += dm) {
+        const int32_t *hu = g.run_user + run_lo + pre;
+        const float *hv = g.val + t_lo + pre;
+        float *qrow = qs + (size_t)(hot_item - c_base) * K;
+        float *bip = bis + (hot_item - c_base);
+        int *tok = ctl + CTL_TOKEN + seg, *front = ctl + CTL_FRONT + seg, *fuser = ctl + CTL_FUSER + seg;
         const int32_t base = m * PA_B;
         const int32_t nb = nh - base < PA_B ? nh - base : PA_B;
         // entry j of the batch lives in lanes j and j + 32 (entries past nb repeat the last one and are never applied)
         const int32_t ej = col < nb ? col : nb - 1;
         const int32_t uj = hu[base + ej];           // the segment's users and ratings come straight from the grid arrays
+        if (MULTI && seg > 0) {   // the earlier segments must be done for this batch's users before their rows are loaded
+            const int32_t last_user = __builtin_amdgcn_readlane(uj, PA_B - 1);
+            for (int spins = 0; hot_frontier(ctl, seg) < last_user; ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         const float buj = __hip_atomic_load(&b_u[uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const float rest = hv[base + ej] - b - buj;
         PF_T(a0);
@@ -693,7 +817,7 @@ __device__ __forceinline__ void phase_a_gram(const int32_t *__restrict__ hu, con
         PF_T(a2);
         PF_ADD(21, a1, a2);
         // 4. the wave's turn
-        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN], __ATOMIC_RELAXED,
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(tok, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
             if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
             __builtin_amdgcn_s_sleep(2);
@@ -759,7 +883,7 @@ __device__ __forceinline__ void phase_a_gram(const int32_t *__restrict__ hu, con
             for (int c = 0; c < KC; ++c) qrow[lane + 64 * c] = qn[c];
             *sink_ptr(bip, ctl, lane) = bi;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sink_ptr(tok, ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_s_setprio(0);
         PF_T(a6);
@@ -788,36 +912,47 @@ __device__ __forceinline__ void phase_a_gram(const int32_t *__restrict__ hu, con
         // The batch's users are done once these stores are: publish it.  Batches are published in order (the frontier
         // is "every user of the segment up to this one"), so a wave may have to let an earlier batch go first.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_FRONT], __ATOMIC_RELAXED,
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(front, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
             if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         {
             const int32_t last_user = m + 1 == nbatch ? 0x7fffffff : __builtin_amdgcn_readlane(uj, PA_B - 1);
-            __hip_atomic_store(sink_ptr(&ctl[CTL_FUSER], ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sink_ptr(fuser, ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __hip_atomic_store(sink_ptr(&ctl[CTL_FRONT], ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sink_ptr(front, ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the rest's gate: the minimum over all segments as this wave sees it now - never above the truth (the
+            // words only grow), and raised with an atomic max so that a late, lower value cannot pull it back
+            if constexpr (MULTI) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int32_t fmin = hot_frontier(ctl, MAXSEG);
+                atomicMax(sink_ptr(&ctl[CTL_FMIN], ctl, lane), fmin);
+            } else {   // batches are published in order: the one word only grows
+                __hip_atomic_store(sink_ptr(&ctl[CTL_FMIN], ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         PF_T(a7);
         PF_ADD(26, a6, a7);
         PF_INC(27, 1);
-    }
+    }   // batches
+    }   // segments
 }
 
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
-// Runs [run_lo, run_lo + n_hot_blk) are the block's hot segment (one single-rating run per user who rated the
-// stripe's most rated item, see mfsgd_grid_create); the same users' other ratings follow in the rest of the block,
-// so the segment is finished - stores drained, barrier - before the rest starts.  FASTA: the segment goes through
-// the hot-item pipeline (phase_a_gram) when the launch gave it LDS row buffers; otherwise it is walked like any other
-// run, through the item's tickets.
+// Runs [run_lo, run_lo + n_hot_blk) are the block's hot segments, one after the other (segment s: one single-rating run
+// per user who rated hot item s of the stripe, by user; see mfsgd_grid_create_opt); the same users' other ratings
+// follow in the rest of the block.  A user may sit in several segments and in the rest, so each of these PASSES is
+// finished - stores drained, barrier - before the next starts.  FASTA: the hot segments go through the hot-item
+// pipeline (phase_a_gram) when the launch gave it LDS row buffers, concurrently with the rest behind its user
+// frontier; otherwise they are walked like any other run, through the items' tickets.
 template <typename T, int KC, bool STAGE, bool FAST, bool FASTA>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
                                               int *tick_done, T *qs, T *bis, int32_t *err, int *rt_u, int *rt_t,
-                                              int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, int32_t hot_item,
-                                              char *abuf, uint32_t abuf_bytes, int n_abuf PF_PARAM)
+                                              int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, char *abuf,
+                                              uint32_t abuf_bytes, int n_abuf PF_PARAM)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
@@ -826,22 +961,50 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     if (width > g.ibp) width = g.ibp;
     for (int i = tid; i < width; i += blockDim.x) tick_done[i] = 0;
     const bool uniq = FAST || g.user_unique;     // host side: FAST kernels are only launched on user-unique grids
-    int32_t seg_lo = run_lo, seg_hi = n_hot_blk > 0 ? run_lo + n_hot_blk : run_hi;
-    bool gated = false;   // the pipeline walks the hot segment WHILE the other waves walk the rest behind its frontier
+    int32_t cnt[MAXSEG];                         // lengths of the block's hot segments (wave-uniform)
+    // a stripe with ONE hot item needs no look at the per-segment counts
+    const bool multi = __builtin_amdgcn_readfirstlane(ctl[CTL_HOT + 1]) >= 0;
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s)
+        cnt[s] = n_hot_blk > 0 && multi ? __builtin_amdgcn_readfirstlane(g.blk_seg_cnt[((size_t)r * g.Gc + c) * MAXSEG + s])
+                                        : (s == 0 ? n_hot_blk : 0);
+    // pass p < MAXSEG = hot segment p, pass MAXSEG = the rest: runs [ctl[CTL_BND + p], ctl[CTL_BND + p + 1]).  Every
+    // thread writes the same words and reads back its own wave's stores (the LDS serves a wave in order).
+    {
+        int32_t pre = run_lo;
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s) { ctl[CTL_BND + s] = pre; pre += cnt[s]; }
+        ctl[CTL_BND + MAXSEG] = pre;
+        ctl[CTL_BND + MAXSEG + 1] = run_hi;
+    }
+    bool gated = false;   // the pipeline walks the hot segments WHILE the other waves walk the rest behind its frontier
+    int first_pass = 0;
     if constexpr (FASTA) {
         if (n_abuf > 0 && n_hot_blk > 0) {
             gated = true;
+            first_pass = MAXSEG;
             // every thread, same values; made visible by the barrier behind the first run table below
-            ctl[CTL_TOKEN] = 0;
-            ctl[CTL_FRONT] = 0;
-            ctl[CTL_FUSER] = g.run_user[run_lo] - 1;   // users below the segment's first one have no rating in it
-            seg_lo = seg_hi; seg_hi = run_hi;
+            int32_t pre = run_lo, fmin = 0x7fffffff;
+#pragma unroll
+            for (int s = 0; s < MAXSEG; ++s) {
+                ctl[CTL_TOKEN + s] = 0;
+                ctl[CTL_FRONT + s] = 0;
+                // users below the segment's first one have no rating in it; an empty segment holds nobody back
+                const int32_t f0 = cnt[s] > 0 ? g.run_user[pre] - 1 : 0x7fffffff;
+                ctl[CTL_FUSER + s] = f0;
+                fmin = f0 < fmin ? f0 : fmin;
+                pre += cnt[s];
+            }
+            ctl[CTL_FMIN] = fmin;
         }
     }
     if (uniq) {
-    for (;;) {   // the hot segment (unless the pipeline took it), then the rest
-    // one trip unless the segment has more than RT_CAP runs (and one trip for an empty rest behind a pipelined segment)
-    for (int32_t lo = seg_lo; lo < seg_hi || (gated && lo == seg_lo); lo += RT_CAP) {
+    for (int pass = first_pass; pass <= MAXSEG; ++pass) {   // the hot segments (unless the pipeline took them), then the rest
+    const int32_t seg_lo = __builtin_amdgcn_readfirstlane(ctl[CTL_BND + pass]);
+    const int32_t seg_hi = __builtin_amdgcn_readfirstlane(ctl[CTL_BND + pass + 1]);
+    const bool rest_pass = pass == MAXSEG;
+    // one trip unless the pass has more than RT_CAP runs (and one trip for an empty rest behind pipelined segments)
+    for (int32_t lo = seg_lo; lo < seg_hi || (gated && rest_pass && lo == seg_lo); lo += RT_CAP) {
     const int32_t nr = seg_hi - lo < RT_CAP ? seg_hi - lo : RT_CAP;
     // the chunk's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
     for (int i = tid; i <= nr + 1; i += blockDim.x) {
@@ -852,12 +1015,16 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
     if constexpr (FASTA) {
-        if (gated && lo == run_lo + n_hot_blk) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segment first
+        if (gated && lo == seg_lo) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segments first
             const int32_t t_lo = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);   // single-rating runs: rating = t_lo + i
-            phase_a_gram<KC>(g.run_user + run_lo, g.val + t_lo, n_hot_blk, (float *)P, (float *)b_u, (float)b, (float)alpha,
-                             (float)beta1, (float)beta2, variant, (float *)qs + (size_t)(hot_item - c_base) * k,
-                             (float *)bis + (hot_item - c_base), (float *)abuf, abuf_bytes / 4, n_abuf < nw ? n_abuf : nw,
-                             ctl, err PF_PASS);
+            if (multi)
+                phase_a_gram<KC, true>(g, run_lo, t_lo, c_base, (float *)P, (float *)b_u, (float)b, (float)alpha,
+                                       (float)beta1, (float)beta2, variant, (float *)qs, (float *)bis, (float *)abuf,
+                                       abuf_bytes / 4, n_abuf < nw ? n_abuf : nw, ctl, err PF_PASS);
+            else
+                phase_a_gram<KC, false>(g, run_lo, t_lo, c_base, (float *)P, (float *)b_u, (float)b, (float)alpha,
+                                        (float)beta1, (float)beta2, variant, (float *)qs, (float *)bis, (float *)abuf,
+                                        abuf_bytes / 4, n_abuf < nw ? n_abuf : nw, ctl, err PF_PASS);
         }
     }
     {
@@ -874,10 +1041,10 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
             if constexpr (FASTA) {
-                if (gated && jj < nr) {   // the user's row may be loaded once the hot segment is done up to this user
+                if (gated && jj < nr) {   // the user's row may be loaded once every hot segment is done up to this user
                     const int32_t u = __builtin_amdgcn_readfirstlane(x.u);
                     for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                                            &ctl[CTL_FUSER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < u; ++spins) {
+                                            &ctl[CTL_FMIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < u; ++spins) {
                         if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
@@ -918,14 +1085,12 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         }
 #undef MF_STEP
     }
-    if (lo + RT_CAP < seg_hi || seg_hi != run_hi) {   // another chunk or the rest of the block follows: new table,
+    if (lo + RT_CAP < seg_hi || !rest_pass) {   // another chunk or another pass follows: new table,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // and the segment's user rows are stored before the same users' runs load them
         __syncthreads();
     }
     }   // chunks
-    if (seg_hi == run_hi) break;
-    seg_lo = seg_hi; seg_hi = run_hi;
-    }   // segments
+    }   // passes
     }   // uniq
     if (!FAST) {
     if (!uniq) {
@@ -1008,11 +1173,13 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
     unsigned long long pf[PF_SLOTS] = {};
 #endif
     const int32_t n_hot_blk = __builtin_amdgcn_readfirstlane(g.blk_hot_cnt[r * g.Gc + c]);
+    if (threadIdx.x < MAXSEG) ctl[CTL_HOT + threadIdx.x] = g.col_hot[(size_t)c * MAXSEG + threadIdx.x];
+    __syncthreads();
     process_block<T, KC, STAGE, false, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
                                               qs, bis, s.err, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
                                               __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
                                               __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), n_hot_blk,
-                                              -1, nullptr, 0, 0 PF_PASS);
+                                              nullptr, 0, 0 PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -1024,8 +1191,8 @@ template <typename T, int KC, bool STAGE, bool FAST, int WPS>
 __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
-    // the hot-item pipeline needs fp32 MFMA, 128 registers and row buffers in LDS (lp.n_abuf > 0)
-    constexpr bool FASTA = FAST && STAGE && sizeof(T) == 4 && KC <= 2 && WPS == 4;
+    // the hot-item pipeline needs fp32 MFMA, k = 64 / 128 / 256, 128 registers and row buffers in LDS (lp.n_abuf > 0)
+    constexpr bool FASTA = FAST && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && WPS == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
@@ -1067,11 +1234,12 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
             mine += empty ? 0 : 1;
         }
         atomicAdd(&ctl[CTL_REMAIN], mine);
+        if (tid < MAXSEG) ctl[CTL_HOT + tid] = g.col_hot[(size_t)c * MAXSEG + tid];   // the stripe's hot items
         stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
         int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
-        const int32_t hot_item = __builtin_amdgcn_readfirstlane(g.col_hot[c]);
+
         for (;;) {
             if (sched_wave) {
                 int32_t found = -1;
@@ -1157,7 +1325,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                                                      ctl, tick_done, qs, bis, s.err, (int *)(smem + lp.rt_u),
                                                      (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
                                                      __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
-                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]), hot_item,
+                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]),
                                                      smem + lp.abuf, lp.abuf_bytes, lp.n_abuf PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
@@ -1203,15 +1371,18 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     MF_HIP(hipGetDeviceProperties(&prop, G->device));
     // two workgroups per CU only pay when there are more stripes than CUs and two stripes fit the LDS of one
     constexpr bool can8 = WAVES_PER_SIMD(T, KC) == 8;
-    const bool wps8 = can8 && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
+    // ... unless the grid has hot segments and their pipeline can run: it needs the 128-register build, and hot segments
+    // that go through the tickets cost more than the second workgroup gains
+    const bool pipe = fast && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
+                      lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs).n_abuf > 0;
+    const bool wps8 = can8 && !pipe && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
     auto kern = fast ? k_epoch_free<T, KC, STAGE, true, 4> : k_epoch_free<T, KC, STAGE, false, 4>;
     if constexpr (can8) {
         if (wps8) kern = fast ? k_epoch_free<T, KC, STAGE, true, 8> : k_epoch_free<T, KC, STAGE, false, 8>;
     }
-    // the hot-item pipeline (phase_a_gram): fp32, k = 64 or 128, the 128-register build, and as many row buffers as
+    // the hot-item pipeline (phase_a_gram): fp32, k = 64, 128 or 256, the 128-register build, and as many row buffers as
     // the LDS left by the stripe holds (at most G->hot_bufs); without a buffer the hot segments take the ticket path
-    if (!wps8 && fast && STAGE && sizeof(T) == 4 && KC <= 2 && G->info.n_hot > 0 && G->hot_bufs > 0)
-        lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs);
+    if (pipe) lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs);
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     if (n_wg <= 0) {
         int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
@@ -1246,7 +1417,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt};
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->blk_seg_cnt};
     const bool dynamic = schedule == 1;
     const size_t cap = LDS_CAP;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
@@ -1279,7 +1450,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt};
+                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt, g->blk_seg_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1322,7 +1493,7 @@ int mfsgd_grid_col_hot(const mfsgd_grid *g, int32_t *h_col_hot, void *stream)
 {
     MF_ARG(g && h_col_hot, "grid_col_hot: null pointer");
     hipStream_t st = as_stream(stream);
-    MF_HIP(hipMemcpyAsync(h_col_hot, g->col_hot, sizeof(int32_t) * (size_t)g->info.Gc, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(h_col_hot, g->col_hot, sizeof(int32_t) * (size_t)g->info.Gc * MAXSEG, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     return MFSGD_OK;
 }
@@ -1380,13 +1551,14 @@ int mfsgd_grid_get_info(const mfsgd_grid *g, mfsgd_grid_info *info)
     return MFSGD_OK;
 }
 
-// allow_hot: order 1 only - store each block's ratings of the stripe's hot item as a segment of their own in front.
+// hot_items > 0: order 1 only - store each block's ratings of the stripe's hot items as segments of their own in front.
 // Returns 1 (no error) when that layout is impossible because a (user, hot item) pair occurs twice: the caller
 // then builds without hot segments.
 static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
-                      int32_t ibp, int32_t order, int32_t hot_min_per_block, void *stream, mfsgd_grid **out)
+                      int32_t ibp, int32_t order, int32_t hot_items, int32_t hot_min_per_block, bool need_share,
+                      void *stream, mfsgd_grid **out)
 {
-    const bool allow_hot = hot_min_per_block > 0;
+    const bool allow_hot = hot_items > 0;
     MF_ARG(out, "grid_create: null out");
     *out = nullptr;
     MF_ARG(n >= 0 && n < ((int64_t)1 << 31) - 1, "grid_create: n=%lld must fit int32", (long long)n);
@@ -1394,7 +1566,7 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_ARG(order == 0 || order == 1, "grid_create: order must be 0 or 1");
     MF_ARG(n == 0 || samples, "grid_create: null samples");
     const int64_t Gr = (n_users + ubp - 1) / ubp, Gc = (n_items + ibp - 1) / ibp, nb = Gr * Gc;
-    MF_ARG(nb < ((int64_t)1 << 30), "grid_create: %lld x %lld blocks is too many", (long long)Gr, (long long)Gc);
+    MF_ARG(nb < ((int64_t)1 << 28), "grid_create: %lld x %lld blocks is too many", (long long)Gr, (long long)Gc);
     hipStream_t st = as_stream(stream);
     mfsgd_grid *G = new mfsgd_grid();
     struct Guard { mfsgd_grid *g; ~Guard() { if (g) mfsgd_grid_destroy(g); } } guard{G};
@@ -1406,9 +1578,11 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->blk_run_ptr, (size_t)nb + 1));
     MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
-    MF_HIP(dalloc(&G->col_hot, (size_t)Gc)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
-    MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc, st));
+    MF_HIP(dalloc(&G->col_hot, (size_t)Gc * MAXSEG)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
+    MF_HIP(dalloc(&G->blk_seg_cnt, (size_t)nb * MAXSEG));
+    MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc * MAXSEG, st));
     MF_HIP(hipMemsetAsync(G->blk_hot_cnt, 0, sizeof(int32_t) * (size_t)nb, st));
+    MF_HIP(hipMemsetAsync(G->blk_seg_cnt, 0, sizeof(int32_t) * (size_t)nb * MAXSEG, st));
     MF_HIP(dalloc(&G->row_lock, ((size_t)Gr + 3) & ~(size_t)3));
     MF_HIP(dalloc(&G->counters, 16));
     MF_HIP(dalloc(&G->col_clock, (size_t)Gc * 2 + PF_SLOTS));
@@ -1450,11 +1624,12 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
             hipLaunchKernelGGL(k_item_deg_raw, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, deg.as<int32_t>());
             MF_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
-                               (int64_t)hot_min_per_block * Gr, G->col_hot);
+                               std::min<int32_t>(hot_items, MAXSEG), (int64_t)hot_min_per_block * Gr, need_share ? 1 : 0,
+                               G->col_hot);
             MF_LAUNCH_CHECK();
             MF_HIP(hipStreamSynchronize(st));
         }
-        // block key with the hot bit (col_hot is all -1 without hot segments: every key is odd)
+        // block key with the class (col_hot is all -1 without hot segments: every rating is of class MAXSEG)
         hipLaunchKernelGGL(k_hot_block_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, (int32_t)Gc, G->col_hot,
                            bk0.as<uint32_t>());
         MF_LAUNCH_CHECK();
@@ -1466,7 +1641,7 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
                            bk1.as<uint32_t>());
         MF_LAUNCH_CHECK();
         rc = sort_pairs_t(bk1.as<uint32_t>(), bk0.as<uint32_t>(), ix1.as<int32_t>(), ix0.as<int32_t>(), n,
-                          bits_for((uint64_t)(2 * nb)), st);
+                          bits_for((uint64_t)(NCLS * nb)), st);
         if (rc) return rc;
         idx_sorted = ix0.as<int32_t>();   // sorted keys now in bk0
         MF_HIP(hot.alloc((size_t)n));
@@ -1491,7 +1666,7 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
         MF_HIP(dup.alloc(4));
         MF_HIP(hipMemsetAsync(dup.p, 0, 4, st));
         hipLaunchKernelGGL(k_hot_count, dim3(nblk(n)), dim3(256), 0, st, bkey, user.as<int32_t>(), hot.as<uint8_t>(), n,
-                           G->blk_hot_cnt, dup.as<int32_t>());
+                           G->blk_seg_cnt, G->blk_hot_cnt, dup.as<int32_t>());
         MF_LAUNCH_CHECK();
         int32_t hd = 0;
         MF_HIP(hipMemcpyAsync(&hd, dup.p, 4, hipMemcpyDeviceToHost, st));
@@ -1574,11 +1749,12 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     }
     // 5b. hot segments: how many stripes have one, how many ratings they hold
     if (with_hot) {
-        std::vector<int32_t> h_hot((size_t)Gc), h_cnt((size_t)nb);
-        MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> h_hot((size_t)Gc * MAXSEG), h_cnt((size_t)nb);
+        MF_HIP(hipMemcpyAsync(h_hot.data(), G->col_hot, sizeof(int32_t) * (size_t)Gc * MAXSEG, hipMemcpyDeviceToHost, st));
         MF_HIP(hipMemcpyAsync(h_cnt.data(), G->blk_hot_cnt, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
-        for (int32_t v : h_hot) G->info.n_hot_stripes += v >= 0;
+        for (int64_t c = 0; c < Gc; ++c) G->info.n_hot_stripes += h_hot[(size_t)c * MAXSEG] >= 0;
+        for (int32_t v : h_hot) G->info.n_hot_items += v >= 0;
         for (int32_t v : h_cnt) G->info.n_hot += v;
     }
     MF_HIP(hipStreamSynchronize(st));
@@ -1608,19 +1784,23 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
 }
 
 int mfsgd_grid_create_opt(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
-                          int32_t ibp, int32_t order, int32_t hot_min_per_block, void *stream, mfsgd_grid **out)
+                          int32_t ibp, int32_t order, int32_t hot_items, int32_t hot_min_per_block, void *stream,
+                          mfsgd_grid **out)
 {
-    MF_ARG(hot_min_per_block >= 0, "grid_create: hot_min_per_block < 0");
-    int rc = hot_min_per_block > 0
-                 ? grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, hot_min_per_block, stream, out) : 1;
-    if (rc == 1) rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, 0, stream, out);
+    MF_ARG(hot_items >= 0 && hot_items <= MAXSEG, "grid_create: hot_items=%d outside [0,%d]", hot_items, MAXSEG);
+    MF_ARG(hot_min_per_block >= 1 || hot_items == 0, "grid_create: hot_min_per_block < 1");
+    int rc = hot_items > 0 ? grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, hot_items, hot_min_per_block,
+                                        false, stream, out) : 1;
+    if (rc == 1) rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, 0, 0, false, stream, out);
     return rc;
 }
 
 int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items, int32_t ubp,
                       int32_t ibp, int32_t order, void *stream, mfsgd_grid **out)
 {
-    return mfsgd_grid_create_opt(samples, n, stride, n_users, n_items, ubp, ibp, order, 1, stream, out);
+    int rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, 1, 1, true, stream, out);
+    if (rc == 1) rc = grid_build(samples, n, stride, n_users, n_items, ubp, ibp, order, 0, 0, false, stream, out);
+    return rc;
 }
 
 int mfsgd_hip_epoch_f32(mfsgd_grid *g, int32_t k, float *P, float *Q, float *b_u, float *b_i, float b, const float *z,

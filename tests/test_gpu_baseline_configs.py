@@ -44,13 +44,13 @@ def orc():
 
 
 def _model(ra, name, *, hot_buffers=None, deterministic=False, n_threads=15, renumber="balanced", grid=None, k=None,
-           init_seed=1):
+           init_seed=1, hot_items=1):
     """ExplicitMF on the named workload: data generated on the GPU, ids renumbered, grid built, factors drawn."""
     import torch
     import workloads
     train, test, U, I, kk = workloads.synth(torch, name)
     m = ra.ExplicitMF(n_threads=n_threads, n_factors=k or kk, alpha=HP[0], beta1=HP[1], beta2=HP[2], implicit="none",
-                      deterministic=deterministic, hot_buffers=hot_buffers, grid=grid, verbose=False)
+                      deterministic=deterministic, hot_buffers=hot_buffers, grid=grid, hot_items=hot_items, verbose=False)
     m.load_samples_from_device(train, test, U, I)
     np.random.seed(20240611)
     if renumber == "balanced":
@@ -122,7 +122,7 @@ def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
     same initial factors, same number of epochs at the reference's constant alpha = 0.006:
       fixed     deterministic=True: the reference's 16 x 16 grid, file order inside a block, row-major block order;
       tickets   on-GPU free-block schedule on a 288 x 384 grid, every rating through the item tickets (no hot segments);
-      pipeline  the same schedule and grid with hot segments, walked by the hot-item pipeline.
+      pipeline  the same schedule and grid with up to three hot segments per block, walked by the hot-item pipeline.
     All three are sequential inside a block; they differ in the block grid and the block order only.
     The gate is asserted on the trained model: at every epoch of the last quarter.
     profiles/r2_rmse_parity.txt holds 30-epoch trajectories (profiles/rmse_gate.py): on the plateau the orders agree to
@@ -135,7 +135,7 @@ def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
     runs, grids = {}, {}
     for tag, kw in (("fixed", dict(deterministic=True, n_threads=15, renumber="random")),
                     ("tickets", dict(hot_buffers=0, renumber="random", grid=(288, 384))),
-                    ("pipeline", dict(renumber="random", grid=(288, 384)))):
+                    ("pipeline", dict(renumber="random", grid=(288, 384), hot_items=3))):
         m, g = _model(ra, "ml25m", **kw)
         assert m.n_factors == 128
         if tag == "fixed":
@@ -144,6 +144,7 @@ def test_ml25m_k128_rmse_gate_fixed_vs_free_block(ra, orc):
             assert g.info.order == 1 and g.info.n_hot == 0
         else:                       # 384 stripes of 154 items leave LDS for the pipeline's row buffers
             assert g.info.order == 1 and g.info.n_hot > 1_000_000 and m._pipeline_runs(g.info.Gr, g.info.Gc)
+            assert g.info.n_hot_items > g.info.n_hot_stripes            # several hot items per stripe
         traj = [m.device_errors()]
         ref = log = None
         if tag != "fixed":
@@ -203,9 +204,13 @@ def test_full_size_properties(ra, name, k, hot_buffers):
     r_, c_ = divmod(bsel, g.info.Gc)
     assert items.min() >= c_ * g.info.ibp and items.max() < (c_ + 1) * g.info.ibp
     ru = d["run_user"][int(brp[bsel]):int(brp[bsel + 1])].cpu().numpy()
-    hot_item = int(g.col_hot()[c_])
-    nh = int((items == hot_item).sum())
-    assert (items[:nh] == hot_item).all() and (np.diff(ru[:nh]) > 0).all() and (np.diff(ru[nh:]) > 0).all()
+    pos = 0
+    for hot_item in g.col_hot()[c_]:            # segment after segment: one rating per user, users ascending
+        if hot_item >= 0:
+            nh = int((items == hot_item).sum())
+            assert (items[pos:pos + nh] == hot_item).all() and (np.diff(ru[pos:pos + nh]) > 0).all()
+            pos += nh
+    assert not np.isin(items[pos:], g.col_hot()[c_]).any() and (np.diff(ru[pos:]) > 0).all()
     assert ru.min() >= r_ * g.info.ubp and ru.max() < (r_ + 1) * g.info.ubp
     seen = {}
     for it, tk in zip(items.tolist(), ticks.tolist()):

@@ -159,10 +159,15 @@ def test_prep_edge_cases(ra):
 
 
 # ------------------------------------------------------------------ the block grid (block-local runs + tickets)
-def _expected_grid(s, U, I, ubp, ibp, order):
-    from _order import col_hot_expected, stored_order
+def _expected_grid(s, U, I, ubp, ibp, order, hot=None):
+    from _order import MAX_HOT, col_hot_expected, stored_order
     Gr, Gc = -(-U // ubp), -(-I // ibp)
-    col_hot = col_hot_expected(s, I, ibp) if order == 1 else np.full(Gc, -1)
+    if order != 1:
+        col_hot = np.full((Gc, MAX_HOT), -1)
+    elif hot is None:                 # mfsgd_grid_create: one item per stripe, 1/16 of the stripe
+        col_hot = col_hot_expected(s, I, ibp)
+    else:                             # mfsgd_grid_create_opt: `items` per stripe, min_per_block ratings per block each
+        col_hot = col_hot_expected(s, I, ibp, items=hot[0], min_deg=hot[1] * Gr, need_share=False)
     if order == 1:
         perm, key, hot = stored_order(s, ubp, ibp, Gc, col_hot)
     else:
@@ -202,12 +207,35 @@ def test_grid_arrays_bit_exact(ra, tag, order):
     for name in exp:
         np.testing.assert_array_equal(got[name], exp[name], err_msg=name)
     np.testing.assert_array_equal(gr.col_hot(), col_hot)
-    assert gr.info.n_hot == n_hot and gr.info.n_hot_stripes == (col_hot >= 0).sum()
+    assert gr.info.n_hot == n_hot and gr.info.n_hot_stripes == (col_hot[:, 0] >= 0).sum()
     users_twice = any(len(set(exp["run_user"][a:b])) < b - a
                       for a, b in zip(exp["blk_run_ptr"][:-1], exp["blk_run_ptr"][1:]))
     assert gr.info.user_unique == (1 if order == 1 else (0 if users_twice else 1))
     if order == 0:      # reference order: the stored rows are exactly the reference's concatenated blocks
         np.testing.assert_array_equal(got["item"], g["blocks_concat"][:, 1])
+
+
+@pytest.mark.parametrize("hot", [(3, 4), (8, 1), (1, 32), (0, 0)])
+def test_grid_arrays_bit_exact_with_several_hot_segments(ra, hot):
+    """mfsgd_grid_create_opt: up to `items` hot items per stripe, each a segment of its own in front of every block."""
+    import torch
+    from recommender_amd.SGDRecommender import Grid
+    rng = np.random.default_rng(42)
+    U, I = 3000, 900
+    s = _synthetic(rng, U, I, 200000, lead=True)
+    ubp, ibp = 47, 57                    # 64 x 16 blocks
+    gr = Grid(torch.from_numpy(s).cuda(), U, I, ubp, ibp, order=1, hot_segments=hot)
+    got = gr.export()
+    exp, col_hot, n_hot = _expected_grid(s, U, I, ubp, ibp, 1, hot=hot if hot[0] else (0, 0))
+    for name in exp:
+        np.testing.assert_array_equal(got[name], exp[name], err_msg=name)
+    np.testing.assert_array_equal(gr.col_hot(), col_hot)
+    assert gr.info.n_hot == n_hot and gr.info.n_hot_items == (col_hot >= 0).sum()
+    assert gr.info.n_hot_stripes == (col_hot[:, 0] >= 0).sum() and gr.info.user_unique == 1
+    if hot == (3, 4):
+        assert (col_hot >= 0).sum(1).max() == 3 and n_hot > 8000       # the case means something
+    if hot == (8, 1):
+        assert (col_hot >= 0).sum(1).max() >= 5
 
 
 # ------------------------------------------------------------------ G8: fixed block order, whole model
@@ -252,7 +280,7 @@ def _synthetic(rng, U, I, n, lead=False):
 
 
 def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1, dt=np.float32, tol=1e-4, variant=0,
-                 lead=None, iters=2):
+                 lead=None, iters=2, hot=None):
     """Run `iters` epochs on the GPU with the block order logged, replay that order block by block through the CPU
     oracle's plain sequential kernel (orc_sgd) in the grid's stored order, compare the factors."""
     import torch
@@ -265,12 +293,12 @@ def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1,
     ubp, ibp = -(-U // Gr), -(-I // Gc)
     Gr, Gc = -(-U // ubp), -(-I // ibp)
     d_s = torch.from_numpy(s).cuda()
-    gr = Grid(d_s, U, I, ubp, ibp, order=1)
+    gr = Grid(d_s, U, I, ubp, ibp, order=1, hot_segments=hot)
     assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
     gr.set_hot_buffers(hot_bufs)
     col_hot = gr.col_hot()
-    assert gr.info.n_hot_stripes == (col_hot >= 0).sum()
-    assert all(h < 0 or h // ibp == c for c, h in enumerate(col_hot))
+    assert gr.info.n_hot_stripes == (col_hot[:, 0] >= 0).sum() and gr.info.n_hot_items == (col_hot >= 0).sum()
+    assert all(h < 0 or h // ibp == c for c, row in enumerate(col_hot) for h in row)
     P = rng.normal(scale=1 / k, size=(U, k)).astype(dt)
     Q = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
     y = rng.normal(scale=1 / k, size=(I, k)).astype(dt)
@@ -324,7 +352,7 @@ def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_b
     segment through the item's tickets like any other rating; hot_bufs > 0 sends it through the hot-item pipeline
     (phase_a_gram: Gram tile on the matrix cores + scalar chain), which restates the same sequential updates.  Both
     must agree with the oracle's plain sequential kernel replaying the stored order - there is no relaxed mode.
-    k = 128 and 64, both update orders (sgd / sgd2), segments longer than one batch, longer than the LDS table
+    k = 128, 64 and 256, both update orders (sgd / sgd2), segments longer than one batch, longer than the LDS table
     (1024), shorter than a batch, and fewer waves than buffers."""
     info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs)
     assert info.n_hot > 1000 and info.n_hot_stripes >= 1
@@ -333,10 +361,21 @@ def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_b
     info = _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, lead=True)   # ~1500 per segment
     assert info.n_hot > 2500
     _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 2, "none", hot_bufs=hot_bufs)               # fewer waves than buffers
-    # the other kernels (k not 64 or 128, implicit term, the fixed schedule) take the ticket path whatever hot_bufs says
+    info = _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, lead=True)   # k = 256: 64 lanes per row
+    assert info.n_hot > 1000
+    # several hot items per stripe (mfsgd_grid_create_opt): a user may sit in several segments and in the rest
+    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 16, "none", hot_bufs=hot_bufs, hot=(8, 1))
+    assert info.n_hot_items > info.n_hot_stripes >= 1 and info.n_hot > 5000
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs, hot=(4, 2), variant=1)
+    _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, lead=True, hot=(8, 1))   # segments longer than the LDS table
+    _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, lead=True, hot=(3, 8))
+    # the other kernels (k not 64, 128 or 256, implicit term, the fixed schedule) take the ticket path whatever hot_bufs says
     _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, lead=True)
     _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs)
     _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, schedule=0)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs, hot=(8, 1))
+    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, lead=True, hot=(8, 1))
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, schedule=0, hot=(8, 1))
 
 
 def test_free_block_and_hot_segments_in_float64(ra, orc):
@@ -345,6 +384,7 @@ def test_free_block_and_hot_segments_in_float64(ra, orc):
     _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", dt=np.float64, tol=1e-9)
     _replay_case(ra, orc, 40, 700, 400, 40000, (16, 8), 8, "frozen", dt=np.float64, tol=1e-9)
     _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", schedule=0, dt=np.float64, tol=1e-9)
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", dt=np.float64, tol=1e-9, hot=(8, 1))
 
 
 def test_hot_segment_arguments_and_duplicates(ra):
