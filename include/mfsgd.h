@@ -122,7 +122,8 @@ int mfsgd_hip_renumber_column(const int64_t *values, int64_t n, int32_t *out_ids
  * users x items score matrix is never stored.  score(u,i) = P[u].Q[i], plus b_u[u] + b_i[i] + b when with_bias
  * (the training predictor numba_methods.py:17 without the implicit term).  users[n_batch] are row ids of P;
  * out_items / out_scores are [n_batch][topn], best first, ties to the lower item id; topn in {4, 8, 16};
- * 32 <= k <= 200 (the user tiles and item chunks of a workgroup share the 160 KB of LDS).  Matrix-core (MFMA
+ * 32 <= k <= 256 (the user tiles and item chunks of a workgroup share the 160 KB of LDS: four user tiles per
+ * workgroup up to k = 200, two above - BASELINE config 5 is k = 256).  Matrix-core (MFMA
  * fp32) kernel; asynchronous on `stream`. */
 int mfsgd_hip_topn_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
                        const int32_t *users, int64_t n_batch, int64_t n_items, int32_t k, int32_t with_bias,
@@ -223,7 +224,10 @@ int mfsgd_hip_epoch_f64(mfsgd_grid *g, int32_t k, double *P, double *Q, double *
  * type == 'item', :131 / :142) solves (F^T F + lambda (n_r + 1) I) x = F^T v with F = fixed[col_inds of r]
  * (:133-139) and writes x to latent[r]; a row without entries gets zeros.  `fixed` is only read (the reference
  * copies it, :127).  `fixed` has n_cols rows, the CSR nnz entries: the kernel checks every row range and column
- * index against them and reports a CSR that does not fit instead of reading outside the arrays.  k <= 128,
+ * index against them and reports a CSR that does not fit instead of reading outside the arrays.  k <= 128 (the
+ * k x k normal matrix of a row lives in the registers of one 256-thread workgroup, 64 entries per thread at k = 128;
+ * BASELINE config 5's k = 256 would need 256 per thread and is refused with MFSGD_ERR_ARG - ALS is a "next" row of
+ * SURVEY.md 8(f), the reference's own default is k = 40, ALSRecommender.py:33),
  * lambda > 0 (the reference's defaults 0.0 make its solve singular for short rows).  Synchronises the stream
  * before it returns (a broken CSR or a non-positive pivot is reported as an error). */
 int mfsgd_hip_als_step_f32(float *latent, const float *fixed, const int64_t *row_ptrs, const int32_t *col_inds,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batched scoring + top-N (mfsgd_hip_topn_f32) on the netflix shape: time, TFLOP/s against the fp32 MFMA peak, and
-the same job done by torch (matmul in slabs + topk) beside it.  python profiles/topn_bench.py [n_users] [n]"""
+the same job done by torch (matmul in slabs + topk) beside it.  python profiles/topn_bench.py [n_users] [n] [k]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,6 +9,8 @@ from recommender_amd import _abi
 U, I, k = 480189, 17770, 128
 m = int(sys.argv[1]) if len(sys.argv) > 1 else U
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+if len(sys.argv) > 3:
+    k = int(sys.argv[3])
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 P = torch.randn(U, k, device="cuda", generator=g) * 0.2
 Q = torch.randn(I, k, device="cuda", generator=g) * 0.2

@@ -466,8 +466,8 @@ class ExplicitMF(Recommender):
             raise ValueError("top_n: n must be in [1, 16]")
         nn = 4 if n <= 4 else (8 if n <= 8 else 16)
         dP, dQ = _abi.to_device(user_vecs, "float32"), _abi.to_device(item_vecs, "float32")
-        if int(dP.shape[1]) != int(dQ.shape[1]) or not 32 <= int(dP.shape[1]) <= 200:
-            raise ValueError("top_n: factor matrices must share k in [32, 200]")
+        if int(dP.shape[1]) != int(dQ.shape[1]) or not 32 <= int(dP.shape[1]) <= 256:
+            raise ValueError("top_n: factor matrices must share k in [32, 256]")
         with_bias = b_u is not None and b_i is not None
         dbu = _abi.to_device(b_u, "float32") if with_bias else None
         dbi = _abi.to_device(b_i, "float32") if with_bias else None

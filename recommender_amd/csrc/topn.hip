@@ -6,7 +6,8 @@
 // implicit term) are produced tile by tile on the matrix cores and reduced to a top-N on the fly - the
 // users x items score matrix (34 GB for the netflix shape) is never written.
 //
-// Layout of one workgroup (4 waves): each wave owns 32 users (their factor rows sit in LDS, padded against bank
+// Layout of one workgroup (4 waves; 2 waves for k > 200, where four user tiles plus the item chunks no longer fit the
+// 160 KB of LDS): each wave owns 32 users (their factor rows sit in LDS, padded against bank
 // conflicts), all four walk the same 32-item chunks of Q, staged once per workgroup in LDS (double-buffered).
 // Per chunk a wave computes the 32x32 tile  S^T = Q_chunk . P_tile^T  with v_mfma_f32_32x32x2_f32: with items as
 // MFMA rows and users as MFMA columns a lane ends up holding 16 candidate items of ONE user (its column), so the
@@ -16,7 +17,7 @@
 
 namespace {
 
-constexpr int TN_WAVES = 4;     // waves per workgroup = user tiles per workgroup
+// waves per workgroup = user tiles per workgroup: a template parameter W (4 up to k = 200, 2 up to k = 256)
 constexpr int TN_TILE = 32;     // users per wave, items per chunk
 constexpr int TN_MAX = 16;      // largest N
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ void insert_top(float (&sc)[N], int32_t (&id)[N], flo
     }
 }
 
-template <int N>
+template <int N, int TN_WAVES>
 __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict__ P, const float *__restrict__ Q,
                                                         const float *__restrict__ b_u, const float *__restrict__ b_i,
                                                         float b, const int32_t *__restrict__ users, int64_t n_batch,
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
     }
     // A chunk of Q goes HBM -> registers before the multiply of the previous chunk and registers -> LDS after it,
     // so the load latency hides behind the MFMA loop (one wave per SIMD: nothing else would hide it).
-    constexpr int STG = (TN_TILE * 208 + TN_WAVES * 64 - 1) / (TN_WAVES * 64);   // floats per thread at kpad = 208
+    constexpr int KPAD_MAX = TN_WAVES == 4 ? 208 : 256;
+    constexpr int STG = (TN_TILE * KPAD_MAX + TN_WAVES * 64 - 1) / (TN_WAVES * 64);   // floats per thread at the widest row
     float stg[STG];
     float stg_b = 0.f;
     int32_t src_off[STG], dst_off[STG];   // where this thread's elements of a chunk come from and go to (-1: none)
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
     }
 }
 
-template <int N>
-int launch_topn(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const int32_t *users,
+template <int N, int TN_WAVES>
+int launch_topn_w(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const int32_t *users,
                 int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
                 hipStream_t st)
 {
@@ -179,7 +181,7 @@ int launch_topn(const float *P, const float *Q, const float *b_u, const float *b
     const size_t bytes = ((size_t)(TN_WAVES + 2) * TN_TILE * ld + 2 * TN_TILE) * sizeof(float);
     MF_ARG(bytes <= (size_t)160 * 1024, "topn: k=%d needs %zu bytes of LDS", k, bytes);
     MF_ARG((size_t)TN_TILE * ld >= (size_t)2 * TN_TILE * N, "topn: k=%d too small for N=%d", k, N);
-    auto kern = k_topn<N>;
+    auto kern = k_topn<N, TN_WAVES>;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int64_t per_wg = (int64_t)TN_WAVES * TN_TILE;
     const unsigned grid = (unsigned)((n_batch + per_wg - 1) / per_wg);
@@ -187,6 +189,15 @@ int launch_topn(const float *P, const float *Q, const float *b_u, const float *b
                        kpad, with_bias, out_items, out_scores);
     MF_LAUNCH_CHECK();
     return MFSGD_OK;
+}
+
+template <int N>
+int launch_topn(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const int32_t *users,
+                int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
+                hipStream_t st)
+{
+    if (k <= 200) return launch_topn_w<N, 4>(P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias, out_items, out_scores, st);
+    return launch_topn_w<N, 2>(P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias, out_items, out_scores, st);
 }
 
 }  // namespace
@@ -197,7 +208,7 @@ extern "C" int mfsgd_hip_topn_f32(const float *P, const float *Q, const float *b
 {
     MF_ARG(P && Q && users && out_items && out_scores, "topn: null pointer");
     MF_ARG(!with_bias || (b_u && b_i), "topn: with_bias needs b_u and b_i");
-    MF_ARG(n_batch >= 0 && n_items > 0 && k >= 32 && k <= 200, "topn: bad shape (k in [32,200])");
+    MF_ARG(n_batch >= 0 && n_items > 0 && k >= 32 && k <= 256, "topn: bad shape (k in [32,256])");
     MF_ARG(topn >= 1 && topn <= TN_MAX, "topn: N=%d outside [1,%d]", topn, TN_MAX);
     if (n_batch == 0) return MFSGD_OK;
     hipStream_t st = as_stream(stream);

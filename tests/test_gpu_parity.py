@@ -572,7 +572,9 @@ def test_topn_vs_reference_predict_and_oracle(ra, orc):
         _check_topn(items, scores, g["items"][:, :n], g["scores"][:, :n], 1e-5)
         assert np.array_equal(items[:, 0][g["items"][:, 0] == 5], np.full((g["items"][:, 0] == 5).sum(), 5))
     rng = np.random.default_rng(11)
-    for U, I, k, m in ((300, 1000, 128, 257), (50, 33, 32, 50), (1000, 4097, 200, 130)):
+    # k = 256 (BASELINE config 5) and 201..255 take the two-wave workgroups
+    for U, I, k, m in ((300, 1000, 128, 257), (50, 33, 32, 50), (1000, 4097, 200, 130), (700, 3001, 256, 200),
+                       (100, 500, 230, 65)):
         P = rng.normal(scale=0.2, size=(U, k)).astype(np.float32); Q = rng.normal(scale=0.2, size=(I, k)).astype(np.float32)
         bu = rng.normal(size=U).astype(np.float32); bi = rng.normal(size=I).astype(np.float32)
         users = rng.integers(0, U, size=m).astype(np.int32)
