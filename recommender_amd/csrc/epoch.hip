@@ -498,7 +498,10 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
     PF_T(w0);
-    PF_PIN(h.m_item); PF_PIN(h.m_tick); PF_PIN(h.m_val); PF_PIN(h.p[0]); PF_PIN(h.p[KC - 1]); PF_PIN(h.bu);
+    // The head's loads are waited for HERE, by name: hipcc then counts exactly (s_waitcnt vmcnt(N), N = the loads issued
+    // since - the heads of the two runs behind this one stay in flight).  Left to the rating loop, the wait became a
+    // vmcnt(0) in the loop's preheader (LLVM flushes the counter in front of a loop that only consumes loads).
+    asm volatile("" ::"v"(h.m_item), "v"(h.m_tick), "v"(h.m_val), "v"(h.p[0]), "v"(h.p[KC - 1]), "v"(h.bu));
     PF_T(w1);
     PF_ADD(PF_HEADWAIT, w0, w1);
     PF_INC(PF_RUNS, 1);
@@ -510,9 +513,15 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     int32_t &m_item = h.m_item, &m_tick = h.m_tick;
     float &m_val = h.m_val;
     T *prow = P + (int64_t)u * k;
-    for (int32_t t = t0; t < t1; ++t) {
-        const int32_t slot = (t - t0) & 63;
-        if (slot == 0 && t != t0) load_meta(g, t, t1, lane, m_item, m_tick, m_val);  // runs longer than 64
+    // The head brought the metadata of the run's first 64 ratings.  A longer run reloads it every 64 ratings - OUTSIDE the
+    // rating loop, and waited for on the spot: with a (conditional) load inside the loop hipcc's wait insertion merges
+    // "just reloaded" into every iteration and starts each rating with s_waitcnt vmcnt(0), i.e. every run waited for the
+    // head loads of the run two ahead that were issued a moment ago - a full memory round trip per run, which is what
+    // the three-deep prefetch exists to hide (seen in the ISA; netflix shape 30.1 -> 24.9 ms per epoch).
+    for (int32_t tc = t0;;) {
+    const int32_t te = t1 - tc > 64 ? tc + 64 : t1;
+    for (int32_t t = tc; t < te; ++t) {
+        const int32_t slot = t - tc;
         const int32_t ig = __builtin_amdgcn_readlane(m_item, slot);
         const int32_t il = ig - c_base;
         int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
@@ -614,6 +623,11 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         PF_PIN(p[0]); PF_PIN(p[KC - 1]);
         PF_T(r2);
         PF_ADD(PF_UPDATE, r1, r2);
+    }
+    if (te >= t1) break;
+    tc = te;
+    load_meta(g, tc, t1, lane, m_item, m_tick, m_val);
+    asm volatile("" : "+v"(m_item), "+v"(m_tick), "+v"(m_val));   // wait here, not in the loop
     }
     PF_T(w2);
     if (FAST) {
