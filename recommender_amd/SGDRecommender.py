@@ -97,6 +97,52 @@ HOT_RATING_COST = 0.35      # a rating on the hot-item pipeline against one on t
                             # per-stripe tenure times fitted as 0.094 us * rest + 0.031 us * hot, profiles/r2_col_times.txt)
 
 
+def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None):
+    """What an item's ratings cost in time, for dealing items to stripes (balanced_permutation): its degree, except for
+    the items that lead their stripes.  Where the hot-item pipeline runs, the stripes' hot items - the hot_items * Gc
+    most rated ones, as far as they qualify (ExplicitMF.build_grid) - cost about a third per rating; through the tickets
+    a stripe's most rated item is a serial chain the stripe's other ratings wait behind, and its ratings cost more than
+    the others' (ML-25M shape, 288 x 256: the 33 K-rating items' stripes took 11.6 ms against a median of 8.6 ms with
+    equal counts; 10.0 ms per epoch with the chain counted five-fold).  None = plain degrees."""
+    deg = np.asarray(deg)
+    if len(deg) > (1 << 21):
+        return None
+    top = np.argsort(-deg, kind="stable")
+    if pipeline_runs and hot_items > 0:
+        top = top[:hot_items * Gc]
+        top = top[deg[top] >= max(256, 32 * Gr)]
+        w = HOT_RATING_COST if weight is None else float(weight)
+    else:
+        top = top[:Gc]
+        w = CHAIN_RATING_COST if weight is None else float(weight)
+    if w == 1.0 or not len(top):
+        return None
+    cost = deg.astype(np.float64)
+    cost[top] *= w
+    return cost
+
+
+def interleave_stripes(new_id, width, world):
+    """Renumber the stripes of a dealing so that stripe c of the deal becomes stripe (c mod world) * per + c // world
+    (per = stripes per shard): balanced_permutation fills stripe 0 with the most rated item, stripe 1 with the next,
+    and so on, and the DSGD ring cuts the items into `world` CONTIGUOUS shards - without this the first shard holds
+    all the longest chains and every sub-epoch waits for the rank that has it (netflix shape, 8 ranks, one rank's
+    sub-epochs: 4.5 ms on shard 0 against 1.9 ms on shard 7)."""
+    new_id = np.asarray(new_id)
+    N = len(new_id)
+    G = -(-N // width)
+    per = -(-G // world)
+    last_full = N - (G - 1) * width == width        # a narrower last stripe has to stay last
+    c = new_id // width
+    movable = G if last_full else G - 1
+    order = [s_ * per + j for j in range(per) for s_ in range(world) if s_ * per + j < movable]   # targets, deal order
+    target = np.arange(G)
+    target[:len(order)] = np.asarray(order) if len(order) == movable else target[:len(order)]
+    if len(order) != movable:                       # shards of unequal size: leave the deal as it is
+        return new_id
+    return target[c] * width + new_id % width
+
+
 def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
     """LDS a free-block workgroup needs for item stripes of `ibp` items (lds_plan in csrc/epoch.hip, kept in
     step with it by tests/test_abi_and_host.py through mfsgd_lds_bytes); `hot_bufs` row buffers of the hot-item
@@ -539,24 +585,7 @@ class ExplicitMF(Recommender):
         du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
         di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
         Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
-        cost = None
-        if self.n_items <= (1 << 21):
-            top = np.argsort(-di, kind="stable")
-            if self._pipeline_runs(Gr, Gc) and self.hot_items > 0:
-                # the stripes' hot items - the hot_items * Gc most rated ones, as far as they qualify (build_grid) - go
-                # through the pipeline, where a rating costs about a third: balance time, not counts
-                top = top[:self.hot_items * Gc]
-                top = top[di[top] >= max(256, 32 * Gr)]
-                w = HOT_RATING_COST if self.hot_cost is None else float(self.hot_cost)
-            else:
-                # through the tickets a stripe's most rated item is a serial chain the stripe's other ratings wait
-                # behind: its ratings cost more than the others' (ML-25M shape, 288 x 256: the 33 K-rating items' stripes
-                # took 11.6 ms against a median of 8.6 ms with equal counts)
-                top = top[:Gc]
-                w = CHAIN_RATING_COST if self.hot_cost is None else float(self.hot_cost)
-            if w != 1.0 and len(top):
-                cost = di.astype(np.float64)
-                cost[top] *= w
+        cost = item_costs(di, Gr, Gc, self._pipeline_runs(Gr, Gc), self.hot_items, self.hot_cost)
         self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):

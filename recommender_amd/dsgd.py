@@ -212,7 +212,7 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     import torch
     import torch.distributed as dist
     from . import _abi
-    from .SGDRecommender import balanced_permutation
+    from .SGDRecommender import balanced_permutation, interleave_stripes, item_costs
 
     train, test, U, I, k = data
     n_train_total = int(train.shape[0])
@@ -227,8 +227,12 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     # users' ratings, P rows and biases (RankWorker).  A real job hands each rank its stripe and nothing else.
     du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
     di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
+    plan0 = DSGDPlan(U, I, world, ubp, ibp)
+    rows = max(1, -(-(plan0.user_range(0)[1] - plan0.user_range(0)[0]) // ubp))
+    cost = item_costs(di, rows, plan0.Gc, pipeline_fits(I, ibp, rows, k, args.hot_buffers), 1,
+                      None if args.hot_cost < 0 else args.hot_cost)
     rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
-    cp = torch.from_numpy(balanced_permutation(di, ibp).astype(np.int32)).cuda()
+    cp = torch.from_numpy(interleave_stripes(balanced_permutation(di, ibp, cost), ibp, world).astype(np.int32)).cuda()
     lib = _abi.lib()
     for t in (train, test):
         _abi.check(lib.mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), 3, _abi.ptr(rp), _abi.ptr(cp), U, I, _abi.stream_ptr()))
