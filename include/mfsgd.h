@@ -151,9 +151,11 @@ typedef struct {
 
 /* order 0: rows keep the reference's relative order inside a block (deterministic parity mode);
  * order 1 (throughput mode): inside a block first the ratings of the stripe's hot item(s), one run per user (the hot
- *          segments, see mfsgd_grid_set_hot_buffers and mfsgd_grid_create_opt), then all other ratings sorted by
- *          user (one run per user), ties in input order.  If a (user, hot item) pair occurs twice the grid is built
- *          without hot segments. */
+ *          segments, see mfsgd_grid_set_hot_buffers and mfsgd_grid_create_opt), then all other ratings, one run per
+ *          user, ties in input order: first the runs of the users with NO rating in a hot segment of this block, by
+ *          user, then the runs of the users with one, by user (the pipeline that walks the hot segments holds only the
+ *          latter back; the others keep the waves busy from the block's first cycle).  A block without hot ratings
+ *          is simply sorted by user.  If a (user, hot item) pair occurs twice the grid is built without hot segments. */
 int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                       int32_t ubp, int32_t ibp, int32_t order, void *stream, mfsgd_grid **out);
 /* The same with the hot segments at the caller's choice: up to hot_items (0 .. MFSGD_MAX_HOT) of a stripe's most rated

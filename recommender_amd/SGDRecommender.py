@@ -151,7 +151,7 @@ def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
     o = up((16 + 128 + 5 * _abi.MAX_HOT + 4) * 4)
     o = up(o + ibp * 4)
     o = up(o + Gr)
-    o = up(o + Gr * 12)
+    o = up(o + Gr * 16)
     o = up(o + ibp * k * esz)
     o = up(o + ibp * esz)
     o = up(o + 1026 * 4)

@@ -46,7 +46,10 @@ using mfprep::DevBuf;
 
 constexpr int PA_MAX_BUFS_DEFAULT = 8;
 constexpr int MAXSEG = MFSGD_MAX_HOT;   // hot segments per block
-constexpr int NCLS = MAXSEG + 1;         // classes of a rating inside its block: hot segment 0 .. MAXSEG-1, the rest
+// classes of a rating inside its block: hot segment 0 .. MAXSEG-1, then the rest - first the ratings of users WITHOUT a
+// rating in a hot segment of this block (class MAXSEG: nothing to wait for while the pipeline walks the segments), then
+// those of the users with one (class MAXSEG + 1: behind the pipeline's user frontier)
+constexpr int NCLS = MAXSEG + 2;
 struct mfsgd_grid {
     mfsgd_grid_info info{};
     int32_t *blk_run_ptr = nullptr, *run_start = nullptr, *run_user = nullptr, *item = nullptr, *tick = nullptr;
@@ -55,6 +58,7 @@ struct mfsgd_grid {
     int32_t *col_hot = nullptr;      // [Gc][MAXSEG] the stripe's hot items (global ids, most rated first; -1: none): item s forms hot segment s of every block of the stripe
     int32_t *blk_hot_cnt = nullptr;  // [Gr*Gc] ratings in the block's hot segments (all of them together)
     int32_t *blk_seg_cnt = nullptr;  // [Gr*Gc][MAXSEG] length of each hot segment (ratings of that item, one per user)
+    int32_t *blk_free_runs = nullptr;  // [Gr*Gc] runs of class MAXSEG: users of the block without a rating in a hot segment
     int32_t max_block_runs = 0;
     int32_t hot_bufs = PA_MAX_BUFS_DEFAULT;   // LDS row buffers the hot-item pipeline may take (0: ticket path only)
     int32_t *row_lock = nullptr;   // [Gr]
@@ -74,7 +78,7 @@ struct GridView {
     int32_t Gr, Gc, ubp, ibp, user_unique, n_cols;
     int64_t n_users, n_items;
     int32_t sentinel_run;  // index of an empty run behind the last real one (its user row is a valid address)
-    const int32_t *col_hot, *blk_hot_cnt, *blk_seg_cnt;   // see mfsgd_grid
+    const int32_t *col_hot, *blk_hot_cnt, *blk_seg_cnt, *blk_free_runs;   // see mfsgd_grid
 };
 
 struct SchedView {
@@ -135,7 +139,7 @@ __global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     bool f = t == 0 || bkey[t] != bkey[t - 1] || user[t] != user[t - 1];
-    if (cls && t > 0) f = f || cls[t] < MAXSEG || cls[t] != cls[t - 1];
+    if (cls && t > 0) f = f || cls[t] < MAXSEG || cls[t] != cls[t - 1];   // (a user is in ONE of the two rest classes)
     flag[t] = f ? 1 : 0;
 }
 
@@ -145,17 +149,40 @@ __global__ void k_item_deg_raw(const int32_t *__restrict__ s, int64_t n, int32_t
     if (t < n) atomicAdd(&deg[s[t * stride + 1]], 1);
 }
 
+// hot_user bit (stripe c, user u): u rated one of stripe c's hot items (that rating sits in a hot segment of u's block)
+__global__ void k_mark_hot_users(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t ibp, int64_t n_users,
+                                 const int32_t *__restrict__ col_hot, uint32_t *hot_user)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t u = s[t * stride], item = s[t * stride + 1];
+    const int32_t c = item / ibp;
+    const int32_t *h = col_hot + (size_t)c * MAXSEG;
+    bool is_hot = false;
+#pragma unroll
+    for (int j = 0; j < MAXSEG; ++j) is_hot = is_hot || h[j] == item;
+    if (!is_hot) return;
+    const uint64_t bit = (uint64_t)c * (uint64_t)n_users + (uint64_t)u;
+    atomicOr(&hot_user[bit >> 5], 1u << (bit & 31));
+}
+
 // order 1 sorts a block's ratings of the stripe's hot items in front of the others, one segment per item:
-// key = NCLS * block + class, class = s for hot item s of the stripe, MAXSEG for every other item
-__global__ void k_hot_block_key(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t Gc,
-                                const int32_t *__restrict__ col_hot, uint32_t *bkey)
+// key = NCLS * block + class, class = s for hot item s of the stripe; every other item: MAXSEG, or MAXSEG + 1 if the
+// user has a rating in a hot segment of the block (hot_user == nullptr: no hot segments at all)
+__global__ void k_hot_block_key(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t Gc, int64_t n_users,
+                                const int32_t *__restrict__ col_hot, const uint32_t *__restrict__ hot_user, uint32_t *bkey)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t b = bkey[t];
     const int32_t item = s[t * stride + 1];
-    const int32_t *h = col_hot + (size_t)(b % (uint32_t)Gc) * MAXSEG;
+    const uint32_t col = b % (uint32_t)Gc;
+    const int32_t *h = col_hot + (size_t)col * MAXSEG;
     uint32_t c = MAXSEG;
+    if (hot_user) {
+        const uint64_t bit = (uint64_t)col * (uint64_t)n_users + (uint64_t)s[t * stride];
+        c += (hot_user[bit >> 5] >> (bit & 31)) & 1u;
+    }
 #pragma unroll
     for (int j = 0; j < MAXSEG; ++j)
         if (h[j] == item) c = j;
@@ -184,14 +211,16 @@ __global__ void k_hot_count(const uint32_t *__restrict__ bkey, const int32_t *__
 }
 
 __global__ void k_run_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ excl,
-                           const int32_t *__restrict__ user, int64_t n, int32_t n_runs, int32_t *run_start,
-                           int32_t *run_user)
+                           const int32_t *__restrict__ user, const uint32_t *__restrict__ bkey,
+                           const uint8_t *__restrict__ cls, int64_t n, int32_t n_runs, int32_t *run_start,
+                           int32_t *run_user, int32_t *blk_free_runs)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { run_start[n_runs] = (int32_t)n; run_start[n_runs + 1] = (int32_t)n; }
     if (t >= n || !flag[t]) return;
     run_start[excl[t]] = (int32_t)t;
     run_user[excl[t]] = user[t];
+    if (cls && cls[t] == MAXSEG) atomicAdd(&blk_free_runs[bkey[t]], 1);
 }
 
 // sorted block keys -> blk_ptr (rating offsets) ; same as prep.hip's k_segment_ptr with int32 out
@@ -381,7 +410,7 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     p.ctl = o; o = up(o + CTL_WORDS * 4);
     p.tick = o; o = up(o + (size_t)ibp * 4);
     p.rowdone = o; o = up(o + (dynamic ? (size_t)Gr : 0));
-    p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 12 : 0));
+    p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 16 : 0));
     p.qs = o; o = up(o + (stage ? (size_t)ibp * k * sizeof(T) : 0));
     p.bis = o; o = up(o + (stage ? (size_t)ibp * sizeof(T) : 0));
     p.rt_u = o; o = up(o + (size_t)(RT_CAP + 2) * 4);
@@ -965,8 +994,8 @@ template <typename T, int KC, bool STAGE, bool FAST, bool FASTA>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
                                               int *tick_done, T *qs, T *bis, int32_t *err, int *rt_u, int *rt_t,
-                                              int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, char *abuf,
-                                              uint32_t abuf_bytes, int n_abuf PF_PARAM)
+                                              int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, int32_t n_free_runs,
+                                              char *abuf, uint32_t abuf_bytes, int n_abuf PF_PARAM)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
@@ -1020,11 +1049,14 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     // one trip unless the pass has more than RT_CAP runs (and one trip for an empty rest behind pipelined segments)
     for (int32_t lo = seg_lo; lo < seg_hi || (gated && rest_pass && lo == seg_lo); lo += RT_CAP) {
     const int32_t nr = seg_hi - lo < RT_CAP ? seg_hi - lo : RT_CAP;
-    // the chunk's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it
+    // the chunk's run table in LDS: entries nr and nr+1 close the last run and form an empty run behind it.  Behind the
+    // pipeline the rest starts with the runs of users WITHOUT a rating in a hot segment (n_free_runs of them): nothing
+    // holds them back; the sign bit marks the others, who wait for the pipeline's user frontier (index() below)
+    const int32_t gate_from = gated && rest_pass ? run_lo + n_hot_blk + n_free_runs : 0x7fffffff;
     for (int i = tid; i <= nr + 1; i += blockDim.x) {
         const int ii = i < nr ? i : nr;
         rt_t[i] = g.run_start[lo + ii];
-        rt_u[i] = i < nr ? g.run_user[lo + i] : 0;
+        rt_u[i] = i < nr ? (g.run_user[lo + i] | (lo + i >= gate_from ? (int32_t)0x80000000 : 0)) : 0;
     }
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
@@ -1055,8 +1087,10 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
             if constexpr (FASTA) {
-                if (gated && jj < nr) {   // the user's row may be loaded once every hot segment is done up to this user
-                    const int32_t u = __builtin_amdgcn_readfirstlane(x.u);
+                const int32_t w = __builtin_amdgcn_readfirstlane(x.u);
+                x.u = w & 0x7fffffff;
+                if (w < 0) {   // the user's row may be loaded once every hot segment is done up to this user
+                    const int32_t u = w & 0x7fffffff;
                     for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                             &ctl[CTL_FMIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < u; ++spins) {
                         if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
@@ -1192,7 +1226,7 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
     process_block<T, KC, STAGE, false, false>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, ctl, tick_done,
                                               qs, bis, s.err, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
                                               __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
-                                              __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), n_hot_blk,
+                                              __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), n_hot_blk, 0,
                                               nullptr, 0, 0 PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
@@ -1211,7 +1245,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
     unsigned char *row_done = (unsigned char *)(smem + lp.rowdone);
-    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][3]: first run, run count, length of the block's hot segment (r, c)
+    int *rowrun = (int *)(smem + lp.rowrun);   // [Gr][4] of block (r, c): first run, end, ratings in hot segments, free runs
     T *qs = (T *)(smem + lp.qs), *bis = (T *)(smem + lp.bis);
     const int tid = threadIdx.x, lane = tid & 63;
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
@@ -1241,9 +1275,10 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
         for (int r = tid; r < g.Gr; r += blockDim.x) {
             const int32_t lo = g.blk_run_ptr[r * g.Gc + c], hi = g.blk_run_ptr[r * g.Gc + c + 1];
             const bool empty = lo == hi;
-            rowrun[3 * r] = lo;
-            rowrun[3 * r + 1] = hi;
-            rowrun[3 * r + 2] = g.blk_hot_cnt[r * g.Gc + c];
+            rowrun[4 * r] = lo;
+            rowrun[4 * r + 1] = hi;
+            rowrun[4 * r + 2] = g.blk_hot_cnt[r * g.Gc + c];
+            rowrun[4 * r + 3] = g.blk_free_runs[r * g.Gc + c];
             row_done[r] = empty ? 1 : 0;
             mine += empty ? 0 : 1;
         }
@@ -1337,9 +1372,10 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
             if (r < 0) break;
             process_block<T, KC, STAGE, FAST, FASTA>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
                                                      ctl, tick_done, qs, bis, s.err, (int *)(smem + lp.rt_u),
-                                                     (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[3 * r]),
-                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 1]),
-                                                     __builtin_amdgcn_readfirstlane(rowrun[3 * r + 2]),
+                                                     (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[4 * r]),
+                                                     __builtin_amdgcn_readfirstlane(rowrun[4 * r + 1]),
+                                                     __builtin_amdgcn_readfirstlane(rowrun[4 * r + 2]),
+                                                     __builtin_amdgcn_readfirstlane(rowrun[4 * r + 3]),
                                                      smem + lp.abuf, lp.abuf_bytes, lp.n_abuf PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
@@ -1431,7 +1467,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     if (in.n == 0 || iters == 0) return MFSGD_OK;
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
-                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->blk_seg_cnt};
+                (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->blk_seg_cnt, G->blk_free_runs};
     const bool dynamic = schedule == 1;
     const size_t cap = LDS_CAP;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
@@ -1464,7 +1500,7 @@ void mfsgd_grid_destroy(mfsgd_grid *g)
 {
     if (!g) return;
     void *ptrs[] = {g->blk_run_ptr, g->run_start, g->run_user, g->item, g->tick, g->val, g->col_order, g->row_lock,
-                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt, g->blk_seg_cnt};
+                    g->counters, g->col_clock, g->col_hot, g->blk_hot_cnt, g->blk_seg_cnt, g->blk_free_runs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1593,7 +1629,8 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->col_hot, (size_t)Gc * MAXSEG)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
-    MF_HIP(dalloc(&G->blk_seg_cnt, (size_t)nb * MAXSEG));
+    MF_HIP(dalloc(&G->blk_seg_cnt, (size_t)nb * MAXSEG)); MF_HIP(dalloc(&G->blk_free_runs, (size_t)nb));
+    MF_HIP(hipMemsetAsync(G->blk_free_runs, 0, sizeof(int32_t) * (size_t)nb, st));
     MF_HIP(hipMemsetAsync(G->col_hot, 0xff, sizeof(int32_t) * (size_t)Gc * MAXSEG, st));
     MF_HIP(hipMemsetAsync(G->blk_hot_cnt, 0, sizeof(int32_t) * (size_t)nb, st));
     MF_HIP(hipMemsetAsync(G->blk_seg_cnt, 0, sizeof(int32_t) * (size_t)nb * MAXSEG, st));
@@ -1628,7 +1665,8 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     if (herr) { mfsgd_set_error("grid_create: a sample lies outside [0,%lld) x [0,%lld)", (long long)n_users, (long long)n_items); return MFSGD_ERR_GRID; }
     int rc;
     int32_t *idx_sorted;
-    DevBuf hot;            // order 1: hot[t] = rating t (sorted position) belongs to its block's hot segment
+    DevBuf hot;            // order 1: hot[t] = class of rating t (sorted position) inside its block, see NCLS
+    DevBuf hot_user;       // bit (stripe, user): the user rated one of the stripe's hot items
     const bool with_hot = order == 1 && allow_hot;
     if (order == 1) {
         if (with_hot) {
@@ -1641,11 +1679,17 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
                                std::min<int32_t>(hot_items, MAXSEG), (int64_t)hot_min_per_block * Gr, need_share ? 1 : 0,
                                G->col_hot);
             MF_LAUNCH_CHECK();
+            const size_t words = (size_t)(((uint64_t)Gc * (uint64_t)n_users + 31) / 32);
+            MF_HIP(hot_user.alloc(words * 4));
+            MF_HIP(hipMemsetAsync(hot_user.p, 0, words * 4, st));
+            hipLaunchKernelGGL(k_mark_hot_users, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, ibp, n_users,
+                               G->col_hot, hot_user.as<uint32_t>());
+            MF_LAUNCH_CHECK();
             MF_HIP(hipStreamSynchronize(st));
         }
-        // block key with the class (col_hot is all -1 without hot segments: every rating is of class MAXSEG)
-        hipLaunchKernelGGL(k_hot_block_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, (int32_t)Gc, G->col_hot,
-                           bk0.as<uint32_t>());
+        // block key with the class (without hot segments col_hot is all -1 and every rating is of class MAXSEG)
+        hipLaunchKernelGGL(k_hot_block_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, (int32_t)Gc, n_users,
+                           G->col_hot, with_hot ? hot_user.as<uint32_t>() : (const uint32_t *)nullptr, bk0.as<uint32_t>());
         MF_LAUNCH_CHECK();
         // LSD: stable by user first, then stable by (block, hot first)
         rc = sort_pairs_t(uk0.as<uint32_t>(), uk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
@@ -1708,7 +1752,8 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     MF_HIP(dalloc(&G->run_start, (size_t)n_runs + 2)); MF_HIP(dalloc(&G->run_user, (size_t)n_runs + 1));
     MF_HIP(hipMemsetAsync(G->run_user + n_runs, 0, 4, st));   // the sentinel run belongs to user 0 and is empty
     hipLaunchKernelGGL(k_run_fill, dim3(nblk(n)), dim3(256), 0, st, flag.as<int32_t>(), excl.as<int32_t>(),
-                       user.as<int32_t>(), n, n_runs, G->run_start, G->run_user);
+                       user.as<int32_t>(), bkey, with_hot ? hot.as<uint8_t>() : (const uint8_t *)nullptr, n, n_runs,
+                       G->run_start, G->run_user, G->blk_free_runs);
     MF_LAUNCH_CHECK();
     DevBuf blk_ptr;
     MF_HIP(blk_ptr.alloc(((size_t)nb + 1) * 4));

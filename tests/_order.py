@@ -1,9 +1,9 @@
 """The stored order of an order-1 block grid (include/mfsgd.h, mfsgd_grid_create / _opt), restated in NumPy for the tests.
 
 Blocks row-major; inside a block first the ratings of the stripe's hot items, one segment per item (segment s = hot
-item s, one rating per user, by user), then all other ratings by user, ties in input order.  Moving a user's hot-item
-ratings in front of OTHER users' ratings changes nothing (updates that share neither user nor item commute exactly), so
-this is the sequential pass over "each user's ratings of the block, hot items first"."""
+item s, one rating per user, by user), then the other ratings: first those of the users who have NO rating in a hot
+segment of this block, by user, then those of the users who have one, by user; ties in input order.  Every user's
+ratings of a block still come hot items first, then in input order."""
 import numpy as np
 
 HOT_SHARE_DIV, HOT_MIN_DEG, MAX_HOT = 16, 256, 8
@@ -35,5 +35,7 @@ def stored_order(s, ubp, ibp, Gc, col_hot):
     for j in range(col_hot.shape[1]):
         cls[s[:, 1] == col_hot[s[:, 1] // ibp, j]] = j
     hot = cls < col_hot.shape[1]
-    perm = np.lexsort((s[:, 0], cls, key))           # stable: block, segment (rest last), user, input order
+    pair = s[:, 0].astype(np.int64) * Gc + s[:, 1] // ibp        # (user, item stripe) = the user inside one block
+    cls[~hot & np.isin(pair, np.unique(pair[hot]))] += 1        # the rest of a user who is in a hot segment goes last
+    perm = np.lexsort((s[:, 0], cls, key))           # stable: block, class, user, input order
     return perm, key, hot

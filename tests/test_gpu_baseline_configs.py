@@ -210,7 +210,13 @@ def test_full_size_properties(ra, name, k, hot_buffers):
             nh = int((items == hot_item).sum())
             assert (items[pos:pos + nh] == hot_item).all() and (np.diff(ru[pos:pos + nh]) > 0).all()
             pos += nh
-    assert not np.isin(items[pos:], g.col_hot()[c_]).any() and (np.diff(ru[pos:]) > 0).all()
+    # the rest: first the runs of the users who are in no hot segment of the block, then the others', each part by user
+    rest = ru[pos:]
+    in_seg = np.isin(rest, ru[:pos])
+    n_free = int((~in_seg).sum())
+    assert not np.isin(items[pos:], g.col_hot()[c_]).any() and len(np.unique(rest)) == len(rest)
+    assert not in_seg[:n_free].any() and in_seg[n_free:].all()
+    assert (np.diff(rest[:n_free]) > 0).all() and (np.diff(rest[n_free:]) > 0).all()
     assert ru.min() >= r_ * g.info.ubp and ru.max() < (r_ + 1) * g.info.ubp
     seen = {}
     for it, tk in zip(items.tolist(), ticks.tolist()):
