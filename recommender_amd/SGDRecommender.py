@@ -93,8 +93,10 @@ def _balanced_by_cost(deg, cost, width):
 
 
 CHAIN_RATING_COST = 5.0     # a rating of a stripe's most rated item on the ticket path against any other rating there
-HOT_RATING_COST = 0.35      # a rating on the hot-item pipeline against one on the ticket path (netflix shape, k = 128:
-                            # per-stripe tenure times fitted as 0.094 us * rest + 0.031 us * hot, profiles/r2_col_times.txt)
+HOT_RATING_COST = 0.8       # a rating on the hot-item pipeline against one on the ticket path, as the dealing should count
+                            # it (netflix shape, k = 128, swept 0.25 .. 1.0: 25.4 ms per epoch at 0.25, 24.1 at 0.7 - 0.85,
+                            # 24.4 at 1.0; the pipeline's own time per rating is a third of the ticket path's, but the
+                            # users of a hot segment hold their other runs back until the pipeline has passed them)
 
 
 def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None):

@@ -1060,6 +1060,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     }
     ctl[CTL_RUN] = 0;  // every thread, same value
     __syncthreads();
+    PF_T(bs);
+    PF_ADD(19, b0, bs);
     if constexpr (FASTA) {
         if (gated && lo == seg_lo) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segments first
             const int32_t t_lo = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);   // single-rating runs: rating = t_lo + i
@@ -1082,12 +1084,21 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         // the branch and re-enters the loop body without lane 0 (seen in the ISA: the run was walked twice).
         // Runs are handed out in stored order and a wave finishes a run before it walks the next one it claimed,
         // so the earliest unfinished rating is always being walked: ticket waits cannot deadlock.
-        auto claim = [&]() { return __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0); };
+        auto claim = [&]() {
+            PF_T(c0);
+            const int32_t jj = __builtin_amdgcn_readlane(atomicAdd(sink_ptr(&ctl[CTL_RUN], ctl, lane), 1), 0);
+            PF_T(c1);
+            PF_ADD(28, c0, c1);
+            return jj;
+        };
         auto index = [&](int32_t jj, RunIdx &x) {
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
             if constexpr (FASTA) {
+                PF_T(i0);
                 const int32_t w = __builtin_amdgcn_readfirstlane(x.u);
+                PF_T(i1);
+                PF_ADD(29, i0, i1);
                 x.u = w & 0x7fffffff;
                 if (w < 0) {   // the user's row may be loaded once every hot segment is done up to this user
                     const int32_t u = w & 0x7fffffff;
@@ -1097,12 +1108,53 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
                         __builtin_amdgcn_s_sleep(4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    PF_T(i2);
+                    PF_ADD(30, i1, i2);
                 }
             }
         };
         // The run loop is unrolled three times and the three heads change roles instead of being copied
         // (cur = nxt; nxt = far cost ~16 v_mov per run): the kernel is bound by VALU issue,
         // and this alone took the netflix epoch from 31.9 to 28.7 ms.
+#ifdef MFSGD_DEPTH1
+        if constexpr (FAST) {
+        // ONE run bound beyond the one being walked; the rows of the runs that will be claimed ~two walks from now are
+        // touched (one dword per 128-byte line) so that the bound run's loads hit L2
+        RunHead<T, KC> h0, h1;
+        RunIdx x;
+        constexpr int LINES = (int)(KC * 64 * sizeof(T) / 128);
+        auto touch = [&](int32_t jj) {
+            int32_t ii = jj + MFSGD_DEPTH1;
+            ii = ii < nr ? ii : nr;
+            const int32_t ut = __builtin_amdgcn_readfirstlane(rt_u[ii]) & 0x7fffffff;
+            const int32_t *row = (const int32_t *)(P + (int64_t)ut * k);
+            return __hip_atomic_load(row + 32 * (lane % LINES), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        };
+        int32_t j0 = claim();
+        index(j0, x);
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, h0);
+        int32_t ta = touch(j0), tb = ta;
+        int32_t j1;
+        PF_T(b1);
+        PF_ADD(PF_PROLOGUE, b0, b1);
+#define MF_STEP1(WALK, LOAD, JW, JN, TV)                                                                                \
+        JN = claim();                                                                                                 \
+        index(JN, x);                                                                                                 \
+        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
+        asm volatile("" ::"v"(TV));                                                                                   \
+        TV = touch(JN);                                                                                               \
+        if (JW >= nr) break;                                                                                          \
+        walk_run<T, KC, STAGE, FAST>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,          \
+                                     tick_done, qs, bis, lane, err PF_PASS);
+        for (;;) {
+            MF_STEP1(h0, h1, j0, j1, ta)
+            MF_STEP1(h1, h0, j1, j0, tb)
+        }
+        asm volatile("" ::"v"(ta), "v"(tb));
+#undef MF_STEP1
+        } else
+#endif
+        {
         RunHead<T, KC> h0, h1, h2;
         RunIdx x;
         int32_t j0 = claim();
@@ -1132,6 +1184,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             j0 = ja; j1 = jb; j2 = jc;
         }
 #undef MF_STEP
+        }
     }
     if (lo + RT_CAP < seg_hi || !rest_pass) {   // another chunk or another pass follows: new table,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // and the segment's user rows are stored before the same users' runs load them
@@ -1575,8 +1628,8 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
     {
         static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
                                               "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure", "poll|ahead=0", "n|ahead=0",
-                                              "sum ahead", "poll|ahead=1", "n|ahead=1", nullptr, "pipe: rows->LDS", "pipe: gram+cols", "pipe: turn wait", "pipe: g",
-                                              "pipe: chain", "pipe: q_nb+pass", "pipe: apply", "pipe: batches", nullptr, nullptr, nullptr, nullptr};
+                                              "sum ahead", "poll|ahead=1", "n|ahead=1", "setup+table", "pipe: rows->LDS", "pipe: gram+cols", "pipe: turn wait", "pipe: g",
+                                              "pipe: chain", "pipe: q_nb+pass", "pipe: apply", "pipe: batches", "claim", "index", "gate wait", nullptr};
         unsigned long long pf[PF_SLOTS];
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
