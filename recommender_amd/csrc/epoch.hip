@@ -143,6 +143,14 @@ __global__ void k_run_flags(const uint32_t *__restrict__ bkey, const int32_t *__
     flag[t] = f ? 1 : 0;
 }
 
+// order 1 walks a user's ratings of a block most rated item first: key = n - degree (stable sort: ties in input order)
+__global__ void k_item_rank_key(const int32_t *__restrict__ s, int64_t n, int32_t stride, const int32_t *__restrict__ deg,
+                                uint32_t *key)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) key[t] = (uint32_t)(n - deg[s[t * stride + 1]]);
+}
+
 __global__ void k_item_deg_raw(const int32_t *__restrict__ s, int64_t n, int32_t stride, int32_t *deg)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1722,12 +1730,12 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     DevBuf hot_user;       // bit (stripe, user): the user rated one of the stripe's hot items
     const bool with_hot = order == 1 && allow_hot;
     if (order == 1) {
+        DevBuf deg;
+        MF_HIP(deg.alloc((size_t)n_items * 4));
+        MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
+        hipLaunchKernelGGL(k_item_deg_raw, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, deg.as<int32_t>());
+        MF_LAUNCH_CHECK();
         if (with_hot) {
-            DevBuf deg;
-            MF_HIP(deg.alloc((size_t)n_items * 4));
-            MF_HIP(hipMemsetAsync(deg.p, 0, (size_t)n_items * 4, st));
-            hipLaunchKernelGGL(k_item_deg_raw, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, deg.as<int32_t>());
-            MF_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_col_hot, dim3(nblk(Gc, 64)), dim3(64), 0, st, deg.as<int32_t>(), n_items, ibp, (int32_t)Gc,
                                std::min<int32_t>(hot_items, MAXSEG), (int64_t)hot_min_per_block * Gr, need_share ? 1 : 0,
                                G->col_hot);
@@ -1744,17 +1752,26 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
         hipLaunchKernelGGL(k_hot_block_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, (int32_t)Gc, n_users,
                            G->col_hot, with_hot ? hot_user.as<uint32_t>() : (const uint32_t *)nullptr, bk0.as<uint32_t>());
         MF_LAUNCH_CHECK();
-        // LSD: stable by user first, then stable by (block, hot first)
-        rc = sort_pairs_t(uk0.as<uint32_t>(), uk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
-                          bits_for((uint64_t)n_users), st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_gather_u32, dim3(nblk(n)), dim3(256), 0, st, bk0.as<uint32_t>(), ix1.as<int32_t>(), n,
+        // LSD: stable by the item's degree (most rated first), then stable by user, then stable by (block, class)
+        hipLaunchKernelGGL(k_item_rank_key, dim3(nblk(n)), dim3(256), 0, st, samples, n, stride, deg.as<int32_t>(),
                            bk1.as<uint32_t>());
         MF_LAUNCH_CHECK();
-        rc = sort_pairs_t(bk1.as<uint32_t>(), bk0.as<uint32_t>(), ix1.as<int32_t>(), ix0.as<int32_t>(), n,
+        rc = sort_pairs_t(bk1.as<uint32_t>(), uk1.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
+                          bits_for((uint64_t)n + 1), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_u32, dim3(nblk(n)), dim3(256), 0, st, uk0.as<uint32_t>(), ix1.as<int32_t>(), n,
+                           uk1.as<uint32_t>());
+        MF_LAUNCH_CHECK();
+        rc = sort_pairs_t(uk1.as<uint32_t>(), uk0.as<uint32_t>(), ix1.as<int32_t>(), ix0.as<int32_t>(), n,
+                          bits_for((uint64_t)n_users), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_u32, dim3(nblk(n)), dim3(256), 0, st, bk0.as<uint32_t>(), ix0.as<int32_t>(), n,
+                           bk1.as<uint32_t>());
+        MF_LAUNCH_CHECK();
+        rc = sort_pairs_t(bk1.as<uint32_t>(), bk0.as<uint32_t>(), ix0.as<int32_t>(), ix1.as<int32_t>(), n,
                           bits_for((uint64_t)(NCLS * nb)), st);
         if (rc) return rc;
-        idx_sorted = ix0.as<int32_t>();   // sorted keys now in bk0
+        idx_sorted = ix1.as<int32_t>();   // sorted keys now in bk0
         MF_HIP(hot.alloc((size_t)n));
         hipLaunchKernelGGL(k_split_hot_key, dim3(nblk(n)), dim3(256), 0, st, bk0.as<uint32_t>(), n, hot.as<uint8_t>());
         MF_LAUNCH_CHECK();

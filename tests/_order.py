@@ -2,8 +2,8 @@
 
 Blocks row-major; inside a block first the ratings of the stripe's hot items, one segment per item (segment s = hot
 item s, one rating per user, by user), then the other ratings: first those of the users who have NO rating in a hot
-segment of this block, by user, then those of the users who have one, by user; ties in input order.  Every user's
-ratings of a block still come hot items first, then in input order."""
+segment of this block, by user, then those of the users who have one, by user.  One user's ratings inside such a run:
+most rated item first (degree over the grid's samples), ties in input order."""
 import numpy as np
 
 HOT_SHARE_DIV, HOT_MIN_DEG, MAX_HOT = 16, 256, 8
@@ -37,5 +37,6 @@ def stored_order(s, ubp, ibp, Gc, col_hot):
     hot = cls < col_hot.shape[1]
     pair = s[:, 0].astype(np.int64) * Gc + s[:, 1] // ibp        # (user, item stripe) = the user inside one block
     cls[~hot & np.isin(pair, np.unique(pair[hot]))] += 1        # the rest of a user who is in a hot segment goes last
-    perm = np.lexsort((s[:, 0], cls, key))           # stable: block, class, user, input order
+    deg = np.bincount(s[:, 1])
+    perm = np.lexsort((-deg[s[:, 1]], s[:, 0], cls, key))   # stable: block, class, user, item degree (descending), input order
     return perm, key, hot
