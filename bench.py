@@ -85,7 +85,8 @@ def run_leg(args, torch, ra, data, k, hot_buffers):
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
                       n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers,
                       **({} if args.hot_items < 0 else {"hot_items": args.hot_items}),
-                      **({} if args.hot_cost < 0 else {"hot_cost": args.hot_cost}), verbose=False)
+                      **({} if args.hot_cost < 0 else {"hot_cost": args.hot_cost}),
+                      **({} if args.hot_min < 0 else {"hot_min": args.hot_min}), verbose=False)
     m.load_samples_from_device(train.clone(), test.clone(), U, I)      # renumbering rewrites the ids in place
     np.random.seed(args.seed % (2 ** 31))
     t0 = time.perf_counter()
@@ -138,6 +139,8 @@ def main():
                     help="cost of a pipeline rating against a ticket-path one when the items are dealt to stripes")
     ap.add_argument("--hot-items", type=int, default=-1,
                     help="hot items (hot segments per block) a stripe may have where the pipeline runs (default: the library's)")
+    ap.add_argument("--hot-min", type=int, default=-1,
+                    help="ratings per block an item needs to become a hot item (default: the model's, 32)")
     ap.add_argument("--hot-buffers", type=int, default=8,
                     help="LDS row buffers of the hot-item pipeline (mfsgd_grid_set_hot_buffers); 0 = every rating "
                          "through the item tickets.  Either way a block is walked sequentially in stored order")

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Time per link of ONE item's update chain: n users each rate item 0 once (plus nothing else), one block.
+python profiles/chain_link.py [k] [n] [mode]   mode: tickets | pipeline | spread (n ratings spread over 64 items: no chain)
+The epoch time / n is the serial cost of one rating of a hot item on that path."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import recommender_amd as ra
+from recommender_amd import _abi
+from recommender_amd.SGDRecommender import Grid
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+mode = sys.argv[3] if len(sys.argv) > 3 else "tickets"
+_abi.require_gpu()
+I = 64
+u = np.arange(n, dtype=np.int32)
+i = (np.arange(n) % I).astype(np.int32) if mode == "spread" else np.zeros(n, np.int32)
+s = torch.from_numpy(np.column_stack([u, i, np.random.default_rng(1).integers(1, 6, n).astype(np.int32)])).cuda()
+m = ra.ExplicitMF(n_threads=0, n_factors=k, implicit="none", grid=(1, 1), verbose=False)
+m.load_samples_from_device(s, s[:16].clone(), n, I)
+m._grid = Grid(m._d_samples, n, I, n, I, order=1, hot_segments=(1, 1) if mode == "pipeline" else 0)
+m.init_params_device(1); m._to_dev()
+m.run_epochs(1); m._grid.status()
+ts = []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); m.run_epochs(1); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+m._grid.status()
+dt = min(ts)
+print(f"k={k} n={n} mode={mode} hot={int(m._grid.info.n_hot)}: epoch {dt*1e3:.3f} ms -> {dt/n*1e9:.1f} ns per rating")

@@ -99,7 +99,7 @@ HOT_RATING_COST = 0.8       # a rating on the hot-item pipeline against one on t
                             # users of a hot segment hold their other runs back until the pipeline has passed them)
 
 
-def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None):
+def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=32):
     """What an item's ratings cost in time, for dealing items to stripes (balanced_permutation): its degree, except for
     the items that lead their stripes.  Where the hot-item pipeline runs, the stripes' hot items - the hot_items * Gc
     most rated ones, as far as they qualify (ExplicitMF.build_grid) - cost about a third per rating; through the tickets
@@ -112,7 +112,7 @@ def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None):
     top = np.argsort(-deg, kind="stable")
     if pipeline_runs and hot_items > 0:
         top = top[:hot_items * Gc]
-        top = top[deg[top] >= max(256, 32 * Gr)]
+        top = top[deg[top] >= max(256, hot_min * Gr)]
         w = HOT_RATING_COST if weight is None else float(weight)
     else:
         top = top[:Gc]
@@ -250,6 +250,7 @@ class ExplicitMF(Recommender):
                  hot_buffers=None,       # LDS row buffers of the hot-item pipeline (None = 8, as many as fit; 0 = ticket path only)
                  hot_items=1,            # hot items (hot segments per block) a stripe may have where the pipeline runs (<= 8)
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
+                 hot_min=32,             # ratings per block (on average) an item needs to become a hot item
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -267,6 +268,7 @@ class ExplicitMF(Recommender):
         self.hot_buffers = 8 if hot_buffers is None else int(hot_buffers)
         self.hot_items = int(hot_items)
         self.hot_cost = hot_cost
+        self.hot_min = int(hot_min)
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -419,7 +421,7 @@ class ExplicitMF(Recommender):
             # one pipeline batch (32 ratings) per block on average (ML-1M shape, blocks of ~130 ratings: 1.26 ms per
             # epoch without hot segments, 1.70 ms with)
             runs = self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp))
-            hot = (self.hot_items, 32) if runs and self.hot_items > 0 else 0
+            hot = (self.hot_items, self.hot_min) if runs and self.hot_items > 0 else 0
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)
         if self.hot_buffers != 8:
             self._grid.set_hot_buffers(self.hot_buffers)
@@ -587,7 +589,7 @@ class ExplicitMF(Recommender):
         du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
         di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
         Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
-        cost = item_costs(di, Gr, Gc, self._pipeline_runs(Gr, Gc), self.hot_items, self.hot_cost)
+        cost = item_costs(di, Gr, Gc, self._pipeline_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min)
         self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):

@@ -369,7 +369,7 @@ int sort_keys_t(K *k_in, K *k_out, int64_t n, int end_bit, hipStream_t st)
 #define PF_PIN(x)
 #endif
 enum { PF_BLOCK = 0, PF_PROLOGUE, PF_ISSUE, PF_HEADWAIT, PF_POLL, PF_UPDATE, PF_TAIL, PF_DRAIN, PF_BARRIER, PF_RUNS,
-       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 32 };
+       PF_RATINGS, PF_SPINS, PF_SCHED, PF_TENURE, PF_POLL0, PF_N0, PF_AHEAD, PF_POLL1, PF_N1, PF_SLOTS = 40 };
 
 constexpr int CTL_WORDS = 16 + 128 + 5 * MAXSEG + 4;  // 16 control words + 128 sink words (see sink_ptr) + the hot segments' words
 // hot-item pipeline, per hot segment s of the block in flight: CTL_TOKEN + s = batches whose chain is done (whose turn it
@@ -799,6 +799,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
             }
         }
     }
+    PF_T(pa0);
     for (int32_t seg = 0; seg < (MULTI ? MAXSEG : 1); ++seg) {
         int32_t nh = 0, hot_item = 0, pre = 0, m0 = 0, dm = 0;
 #pragma unroll
@@ -986,6 +987,9 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
         PF_T(a7);
         PF_ADD(26, a6, a7);
         PF_INC(27, 1);
+#ifdef MFSGD_PROF
+        if (m + 1 == nbatch) { PF_ADD(31, pa0, a7); PF_INC(PF_ISSUE, 1); }   // from the block's start to the segment's last publish
+#endif
     }   // batches
     }   // segments
 }
@@ -1124,44 +1128,6 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         // The run loop is unrolled three times and the three heads change roles instead of being copied
         // (cur = nxt; nxt = far cost ~16 v_mov per run): the kernel is bound by VALU issue,
         // and this alone took the netflix epoch from 31.9 to 28.7 ms.
-#ifdef MFSGD_DEPTH1
-        if constexpr (FAST) {
-        // ONE run bound beyond the one being walked; the rows of the runs that will be claimed ~two walks from now are
-        // touched (one dword per 128-byte line) so that the bound run's loads hit L2
-        RunHead<T, KC> h0, h1;
-        RunIdx x;
-        constexpr int LINES = (int)(KC * 64 * sizeof(T) / 128);
-        auto touch = [&](int32_t jj) {
-            int32_t ii = jj + MFSGD_DEPTH1;
-            ii = ii < nr ? ii : nr;
-            const int32_t ut = __builtin_amdgcn_readfirstlane(rt_u[ii]) & 0x7fffffff;
-            const int32_t *row = (const int32_t *)(P + (int64_t)ut * k);
-            return __hip_atomic_load(row + 32 * (lane % LINES), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        };
-        int32_t j0 = claim();
-        index(j0, x);
-        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, h0);
-        int32_t ta = touch(j0), tb = ta;
-        int32_t j1;
-        PF_T(b1);
-        PF_ADD(PF_PROLOGUE, b0, b1);
-#define MF_STEP1(WALK, LOAD, JW, JN, TV)                                                                                \
-        JN = claim();                                                                                                 \
-        index(JN, x);                                                                                                 \
-        load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
-        asm volatile("" ::"v"(TV));                                                                                   \
-        TV = touch(JN);                                                                                               \
-        if (JW >= nr) break;                                                                                          \
-        walk_run<T, KC, STAGE, FAST>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,          \
-                                     tick_done, qs, bis, lane, err PF_PASS);
-        for (;;) {
-            MF_STEP1(h0, h1, j0, j1, ta)
-            MF_STEP1(h1, h0, j1, j0, tb)
-        }
-        asm volatile("" ::"v"(ta), "v"(tb));
-#undef MF_STEP1
-        } else
-#endif
         {
         RunHead<T, KC> h0, h1, h2;
         RunIdx x;
@@ -1179,11 +1145,18 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         // the next run is claimed (only now: DESIGN.md section 3.1) and its index words are read
 #define MF_STEP(WALK, LOAD, JW, JN)                                                                                     \
         if (JW >= nr) break;                                                                                          \
+        {                                                                                                             \
+        PF_T(s0);                                                                                                     \
         load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
+        PF_T(s1);                                                                                                     \
         walk_run<T, KC, STAGE, FAST>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,          \
                                      tick_done, qs, bis, lane, err PF_PASS);                                          \
+        PF_T(s2);                                                                                                     \
         JN = claim();                                                                                                 \
-        index(JN, x);
+        index(JN, x);                                                                                                 \
+        PF_T(s3);                                                                                                     \
+        PF_ADD(32, s0, s1); PF_ADD(33, s1, s2); PF_ADD(34, s0, s3);                                                     \
+        }
         for (;;) {
             int32_t ja, jb, jc;
             MF_STEP(h0, h2, j0, ja)
@@ -1634,10 +1607,11 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_nnz_start_end, void *st
     MF_HIP(hipStreamSynchronize(st));
 #ifdef MFSGD_PROF
     {
-        static const char *names[PF_SLOTS] = {"block", "prologue", "issue", "headwait", "poll", "update", "tail", "drain",
+        static const char *names[PF_SLOTS] = {"block", "prologue", "pipe: segments", "headwait", "poll", "update", "tail", "drain",
                                               "barrier", "runs", "ratings", "spins", "sched+stripe", "tenure", "poll|ahead=0", "n|ahead=0",
                                               "sum ahead", "poll|ahead=1", "n|ahead=1", "setup+table", "pipe: rows->LDS", "pipe: gram+cols", "pipe: turn wait", "pipe: g",
-                                              "pipe: chain", "pipe: q_nb+pass", "pipe: apply", "pipe: batches", "claim", "index", "gate wait", nullptr};
+                                              "pipe: chain", "pipe: q_nb+pass", "pipe: apply", "pipe: batches", "claim", "index", "gate wait", "pipe: segment done at",
+                                              "load_run issue", "walk_run", "step", nullptr, nullptr, nullptr, nullptr, nullptr};
         unsigned long long pf[PF_SLOTS];
         MF_HIP(hipMemcpy(pf, g->col_clock + 2 * Gc, sizeof(pf), hipMemcpyDeviceToHost));
         MF_HIP(hipMemset(g->col_clock + 2 * Gc, 0, sizeof(pf)));
