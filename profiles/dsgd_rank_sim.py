@@ -24,7 +24,7 @@ if grid:
     Gr, Gc = (int(x) for x in grid.split(","))
     ubp, ibp = -(-U // Gr), -(-I // Gc)
 else:
-    ubp, ibp = dsgd.choose_multi_grid(U, I, n, world, k)
+    ubp, ibp = dsgd.choose_multi_grid(U, I, n, world, k, max_item_degree=int(torch.bincount(train[:, 1].long(), minlength=I).max()))
 du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
 di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
 plan0 = dsgd.DSGDPlan(U, I, world, ubp, ibp)

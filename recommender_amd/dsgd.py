@@ -93,20 +93,38 @@ def gather_items(plan, rank, Q, b_i, dist):
             dist.broadcast(b_i[a0:a1], src=q)
 
 
-def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4):
-    """Block grid for `world` ranks: per sub-epoch a rank works on rows x cols blocks of ~170+ ratings, with
-    up to 256 column stripes per shard (one workgroup each) and a quarter more row stripes than columns.
-    Measured with profiles/dsgd_rank_sim.py (netflix shape, one rank's kernels alone): blocks of ~70 ratings
-    cost world=4 7.7 ms per sub-epoch, blocks of ~170 5.0 ms; world=8 is flat between 12K and 22K blocks."""
-    ring = 0
-    ibp_max = max(1, (120 * 1024 - ring) // ((k + 1) * esz + 4))
-    cols = min(256, max(1, n_items // world))
-    rows = min(cols + cols // 4, max(1, n_users // world))
+# what profiles/dsgd_rank_sim.py measured for ONE rank's sub-epoch kernel on an MI355X (netflix shape, k = 128)
+SUB_EPOCH_BLOCK_US = 15.0       # a block's fixed cost on the stripe's critical path: transition + pipeline fill
+SUB_EPOCH_RATE = 15.0           # ratings per microsecond and workgroup when nothing waits
+CHAIN_LINK_US = (0.12, 0.22)    # one link of an item's chain: hot-item pipeline, item tickets (profiles/r2_chain_link.txt)
+
+
+def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, max_item_degree=None, n_cus=256):
+    """Block grid for `world` ranks.  A rank's sub-epoch walks `rows x cols` blocks, one workgroup per column stripe,
+    and a stripe's tenure is bound by latency, not by throughput: the most rated item's chain (its ratings by this
+    rank's users, serial) plus `rows` block transitions; the ratings themselves only matter when the stripes are few:
+        t(cols) = max(chain + rows * 15 us, ratings per sub-epoch / (cols * 15 per us)),  rows = cols + cols / 8
+    (fits the measured kernels to 5-10 %: netflix shape, world 2 / 4 / 8: 127, 127 and 64 stripes per shard take 11.4,
+    6.2 and 3.0 ms per sub-epoch; 254, 159 and 80 stripes - round 2's earlier rule, "fill every CU" - 13.5, 7.2, 3.5).
+    So: the FEWEST stripes per shard whose throughput term does not exceed the latency term, never more than CUs."""
+    ibp_max = max(1, (120 * 1024) // ((k + 1) * esz + 4))
     per = n_train / float(world * world)
-    want = max(1.0, per / 170.0)
-    if rows * cols > want:
-        f = (want / (rows * cols)) ** 0.5
-        rows, cols = max(1, int(rows * f)), max(1, int(cols * f))
+    if max_item_degree is None:
+        max_item_degree = 0.0016 * n_train          # netflix-like head
+    from .SGDRecommender import lds_bytes
+    best = None
+    cmin = max(1, -(-n_items // (world * ibp_max)))
+    for cols in range(max(cmin, 8), min(n_cus, max(1, n_items // world)) + 1, 4):
+        rows = min(cols + max(1, cols // 8), max(1, n_users // world))
+        ibp = -(-n_items // (cols * world))
+        piped = k in (64, 128) and esz == 4 and lds_bytes(ibp, rows, k, 4, 2) <= 160 * 1024
+        chain = max_item_degree / world * CHAIN_LINK_US[0 if piped else 1]
+        t = max(chain + rows * SUB_EPOCH_BLOCK_US, per / (cols * SUB_EPOCH_RATE))
+        if best is None or t < best[0] - 1e-9:
+            best = (t, rows, cols)
+    if best is None:   # stripes limited by the LDS, more of them than CUs (Yahoo shape): a workgroup takes several in turn
+        best = (0.0, min(n_cus + n_cus // 8, max(1, n_users // world)), cmin)
+    _, rows, cols = best
     ibp = max(1, min(ibp_max, -(-n_items // (cols * world))))
     ubp = max(1, -(-n_users // (rows * world)))
     return ubp, ibp
@@ -220,7 +238,8 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
         Gr, Gc = (int(x) for x in args.grid.split(","))
         ubp, ibp = -(-U // Gr), -(-I // Gc)
     else:
-        ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k)
+        ubp, ibp = choose_multi_grid(U, I, n_train_total, world, k,
+                                     max_item_degree=int(torch.bincount(train[:, 1].long(), minlength=I).max()))
     t0 = time.perf_counter()
     # The bench generates the SAME synthetic data set on every rank (so that 1, 2, 4 and 8 GPUs train on identical
     # ratings) and computes the same load-balancing permutation everywhere; from here on a rank keeps only its own
