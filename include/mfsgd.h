@@ -167,7 +167,7 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
  * block of an order-1 grid sorted by user only).  A rating that goes through the hot-item pipeline
  * (mfsgd_grid_set_hot_buffers) costs about a third of one that goes through the item tickets (netflix shape, k = 128),
  * in batches of 32; hot segments that go through the tickets cost time (a block then starts with a stretch in
- * which every wave waits for the same item).  So a caller that knows the pipeline will run passes (MFSGD_MAX_HOT, 32),
+ * which every wave waits for the same item).  So a caller that knows the pipeline will run passes (1, 64) - ExplicitMF.build_grid does -
  * and one that knows it will not - k other than 64 / 128 / 256, fp64, an implicit term, item stripes that leave no
  * LDS for its row buffers - passes (0, 0).  mfsgd_grid_create is one hot item per stripe of any length, if it
  * carries >= 1/16 of the stripe's ratings. */

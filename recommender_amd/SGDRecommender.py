@@ -99,7 +99,7 @@ HOT_RATING_COST = 0.8       # a rating on the hot-item pipeline against one on t
                             # users of a hot segment hold their other runs back until the pipeline has passed them)
 
 
-def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=32):
+def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64):
     """What an item's ratings cost in time, for dealing items to stripes (balanced_permutation): its degree, except for
     the items that lead their stripes.  Where the hot-item pipeline runs, the stripes' hot items - the hot_items * Gc
     most rated ones, as far as they qualify (ExplicitMF.build_grid) - cost about a third per rating; through the tickets
@@ -250,7 +250,7 @@ class ExplicitMF(Recommender):
                  hot_buffers=None,       # LDS row buffers of the hot-item pipeline (None = 8, as many as fit; 0 = ticket path only)
                  hot_items=1,            # hot items (hot segments per block) a stripe may have where the pipeline runs (<= 8)
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
-                 hot_min=32,             # ratings per block (on average) an item needs to become a hot item
+                 hot_min=64,             # ratings per block (on average) an item needs to become a hot item (two pipeline batches)
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -375,8 +375,10 @@ class ExplicitMF(Recommender):
         160 KB of it.  One 16-wave workgroup per CU on the 128-register build is the default shape: 256 item stripes
         (one round of the 256 CUs) whenever the stripe fits, else 512 (two stripes per workgroup, handed out heaviest
         first).  User stripes: an eighth more than workgroups in flight (row locks are taken at random; swept 256..320:
-        flat, 272-288 best).  Small inputs shrink both so that a block still holds ~128 ratings (per-block cost - lock,
-        fences, barriers - is microseconds)."""
+        flat, 272-288 best).  Small inputs shrink both so that a block still holds ~200 ratings: a stripe's tenure is the
+        chain of its most rated item plus one transition (~7 us: lock, fences, run table, first rows, barrier) per
+        user stripe, so few large blocks beat many small ones until the workgroups run out of ratings (ML-1M shape:
+        93 x 75 blocks 1.26 ms per epoch, 68 x 60 1.18, 56 x 48 1.20)."""
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
@@ -397,7 +399,7 @@ class ExplicitMF(Recommender):
                 ibp0 = -(-I // max(Gc, Gc_min))
                 two = esz == 4 and k <= 128 and lds_bytes(ibp0, 640, k, esz) <= 80 * 1024
                 Gr = min(U, 640 if two else 320)      # Yahoo shape, k=256: 640 -> 320 rows took 276 -> 201 ms
-                want = max(1.0, n / 128.0)
+                want = max(1.0, n / 200.0)
                 if Gr * Gc > want:
                     f = (want / (Gr * Gc)) ** 0.5
                     Gr, Gc = max(1, int(Gr * f)), max(1, int(Gc * f))
@@ -418,8 +420,9 @@ class ExplicitMF(Recommender):
             ubp, ibp = self._choose_grid()
             # hot segments only where the pipeline will walk them: through the item tickets they cost time
             # (ML-25M shape, 288 x 256: 11.8 ms per epoch without them, 13.0 ms with); and only items that fill at least
-            # one pipeline batch (32 ratings) per block on average (ML-1M shape, blocks of ~130 ratings: 1.26 ms per
-            # epoch without hot segments, 1.70 ms with)
+            # two pipeline batches (64 ratings) per block on average: a batch costs ~9 us of row gather and Gram tile
+            # before its first link (ML-1M shape: 93 x 75 blocks 1.26 ms per epoch without hot segments, 1.70 ms with
+            # items of 32+ ratings per block; 64 x 56 blocks 1.18 against 1.41)
             runs = self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp))
             hot = (self.hot_items, self.hot_min) if runs and self.hot_items > 0 else 0
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)

@@ -165,7 +165,7 @@ class RankWorker:
             self.test = test_local.clone()
             self.test[:, 0] -= u0
         rows = max(1, -(-self.nu // plan.ubp))
-        hot = (1, 32) if pipeline_fits(plan.n_items, plan.ibp, rows, k, hot_buffers) else 0
+        hot = (1, 64) if pipeline_fits(plan.n_items, plan.ibp, rows, k, hot_buffers) else 0
         self.grids = []
         for q in range(plan.world):
             i0, i1 = plan.item_range(q)
