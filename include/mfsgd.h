@@ -241,6 +241,24 @@ int mfsgd_hip_als_step_f64(double *latent, const double *fixed, const int64_t *r
                            const double *vals, int64_t n_rows, int64_t n_cols, int64_t nnz, int32_t k, double lambda,
                            void *stream);
 
+/* ---- multi-GPU DSGD ring, host side (SURVEY.md 8(b) `mfsgd_dsgd_*`, 8(e)).  No counterpart in the reference (it has no
+ * multi-device path); the rule is its FPSGD invariant (RayBlockScheduler.py:50-62) one level up: users are cut into
+ * `world` contiguous super-stripes and items into `world` contiguous shards, both on boundaries of the ubp x ibp block
+ * grid; rank g owns the P / b_u rows of user_edges[g] .. user_edges[g+1] for good; an epoch is `world` sub-epochs, in
+ * sub-epoch `step` rank g runs mfsgd_hip_epoch_* on the grid built from ITS users' ratings of shard (g + step) mod world
+ * and then sends that shard's Q / b_i rows (item_edges[q] .. item_edges[q+1]) to rank g-1 and receives the next from rank
+ * g+1 (RCCL send/recv; recommender_amd/dsgd.py over torch.distributed).  These calls touch no device. */
+/* user_edges[world+1], item_edges[world+1] (HOST); Gr_out / Gc_out (may be NULL): the global grid */
+int mfsgd_dsgd_plan(int64_t n_users, int64_t n_items, int32_t world, int32_t ubp, int32_t ibp, int64_t *user_edges,
+                    int64_t *item_edges, int32_t *Gr_out, int32_t *Gc_out);
+/* the shard `rank` holds in sub-epoch `step` (steps count on across epochs), and its two ring neighbours; any may be NULL */
+int mfsgd_dsgd_schedule(int32_t world, int32_t rank, int32_t step, int32_t *shard, int32_t *send_to, int32_t *recv_from);
+/* Block sizes for `world` ranks: the fewest stripes per shard whose throughput term stays below the latency term of a
+ * sub-epoch (the most rated item's chain + one block transition per row stripe).
+ * max_item_degree <= 0: assume a netflix-like head (0.16 % of the ratings); n_cus: 256 on MI355X. */
+int mfsgd_dsgd_choose_grid(int64_t n_users, int64_t n_items, int64_t n_train, int32_t world, int32_t k, int32_t elem_size,
+                           int64_t max_item_degree, int32_t n_cus, int32_t *ubp_out, int32_t *ibp_out);
+
 #ifdef __cplusplus
 }
 #endif

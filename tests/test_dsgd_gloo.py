@@ -105,3 +105,31 @@ def test_choose_multi_grid_shapes():
         assert ibp * (128 + 1) * 4 + ibp * 4 <= 150 * 1024
         per_block = 90_000_000 / (plan.Gr * plan.Gc)
         assert per_block >= 30, (world, plan.Gr, plan.Gc)
+
+
+def test_dsgd_plan_c_abi_matches_the_python_plan():
+    """mfsgd_dsgd_plan / _schedule / _choose_grid (include/mfsgd.h; host-only calls) against DSGDPlan / choose_multi_grid."""
+    import ctypes as C
+    from recommender_amd import _abi
+    lib = _abi.lib()
+    shapes = [(480189, 17770, 90_000_000, 128, 139853), (162541, 59047, 22_500_000, 128, 33797),
+              (1000990, 624961, 225_000_000, 256, 0), (6040, 3706, 900_000, 64, 3085), (943, 1682, 90_000, 32, 500),
+              (50, 7, 300, 8, 0)]
+    for U, I, n, k, top in shapes:
+        for world in (1, 2, 3, 4, 8):
+            ubp, ibp = choose_multi_grid(U, I, n, world, k, max_item_degree=top or None)
+            cu, ci = C.c_int32(), C.c_int32()
+            _abi.check(lib.mfsgd_dsgd_choose_grid(U, I, n, world, k, 4, top, 256, C.byref(cu), C.byref(ci)))
+            assert (cu.value, ci.value) == (ubp, ibp), (U, world, (cu.value, ci.value), (ubp, ibp))
+            plan = DSGDPlan(U, I, world, ubp, ibp)
+            ue, ie = (C.c_int64 * (world + 1))(), (C.c_int64 * (world + 1))()
+            gr, gc = C.c_int32(), C.c_int32()
+            _abi.check(lib.mfsgd_dsgd_plan(U, I, world, ubp, ibp, ue, ie, C.byref(gr), C.byref(gc)))
+            assert list(ue) == plan.user_edges and list(ie) == plan.item_edges and (gr.value, gc.value) == (plan.Gr, plan.Gc)
+            for rank in range(world):
+                for step in range(2 * world + 1):
+                    q, to, frm = C.c_int32(), C.c_int32(), C.c_int32()
+                    _abi.check(lib.mfsgd_dsgd_schedule(world, rank, step, C.byref(q), C.byref(to), C.byref(frm)))
+                    assert (q.value, to.value, frm.value) == (plan.shard_at(rank, step), plan.send_to(rank), plan.recv_from(rank))
+    assert lib.mfsgd_dsgd_schedule(4, 4, 0, None, None, None) != 0          # rank outside the world
+    assert lib.mfsgd_dsgd_plan(10, 10, 0, 1, 1, None, None, None, None) != 0
