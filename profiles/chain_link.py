@@ -29,3 +29,7 @@ for _ in range(3):
 m._grid.status()
 dt = min(ts)
 print(f"k={k} n={n} mode={mode} hot={int(m._grid.info.n_hot)}: epoch {dt*1e3:.3f} ms -> {dt/n*1e9:.1f} ns per rating")
+if os.environ.get("MFSGD_LIBRARY"):      # the instrumented build prints its phase sums from mfsgd_grid_col_times
+    import ctypes as C
+    out = np.zeros((m._grid.info.Gc, 3), dtype=np.int64)
+    _abi.check(_abi.lib().mfsgd_grid_col_times(m._grid.handle, out.ctypes.data_as(C.c_void_p), None))
