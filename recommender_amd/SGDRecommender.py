@@ -102,7 +102,7 @@ HOT_RATING_COST = 0.8       # a rating on the hot-item pipeline against one on t
 def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64):
     """What an item's ratings cost in time, for dealing items to stripes (balanced_permutation): its degree, except for
     the items that lead their stripes.  Where the hot-item pipeline runs, the stripes' hot items - the hot_items * Gc
-    most rated ones, as far as they qualify (ExplicitMF.build_grid) - cost about a third per rating; through the tickets
+    most rated ones, as far as they qualify (ExplicitMF.build_grid) - count HOT_RATING_COST per rating; through the tickets
     a stripe's most rated item is a serial chain the stripe's other ratings wait behind, and its ratings cost more than
     the others' (ML-25M shape, 288 x 256: the 33 K-rating items' stripes took 11.6 ms against a median of 8.6 ms with
     equal counts; 10.0 ms per epoch with the chain counted five-fold).  None = plain degrees."""
