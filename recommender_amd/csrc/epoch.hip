@@ -478,10 +478,10 @@ __device__ __forceinline__ void load_meta(const GridView &g, int32_t t, int32_t 
 
 // Issues the loads of a run's head; nothing here waits, so a caller can keep two runs in flight behind the
 // one it is walking and the HBM latency of the row and of the metadata hides behind that walk.
-// FAST (k a multiple of 64, no implicit term): no lane guard and no optional load, so the loop that calls this
+// FAST != 0 (k a multiple of 64; 1: no implicit term, 2: with the frozen term z): no lane guard and no optional load, so the loop that calls this
 // is straight-line code and hipcc can count vmcnt exactly (with any conditional load in the pipeline it falls
 // back to waiting for the youngest loads, i.e. exposes a full HBM round trip per run).
-template <typename T, int KC, bool FAST>
+template <typename T, int KC, int FAST>
 __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, const T *__restrict__ P,
                                          const T *__restrict__ b_u, const T *__restrict__ z, int k, int lane,
                                          RunHead<T, KC> &h)
@@ -497,6 +497,7 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
         h.p[c] = 0; h.zz[c] = 0;
         if (FAST) {
             h.p[c] = prow[f];
+            if (FAST == 2) h.zz[c] = z[(int64_t)h.u * k + f];
         } else if (f < k) {
             h.p[c] = prow[f];
             if (z) h.zz[c] = z[(int64_t)h.u * k + f];
@@ -527,7 +528,7 @@ __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q
     return e;
 }
 
-template <typename T, int KC, bool STAGE, bool FAST>
+template <typename T, int KC, bool STAGE, int FAST>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
@@ -634,7 +635,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #endif
         PF_INC(PF_RATINGS, 1);
         T pn[KC];
-        const T e = sgd_step<T, KC, !FAST>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
+        const T e = sgd_step<T, KC, FAST != 1>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 // finished - stores drained, barrier - before the next starts.  FASTA: the hot segments go through the hot-item
 // pipeline (phase_a_gram) when the launch gave it LDS row buffers, concurrently with the rest behind its user
 // frontier; otherwise they are walked like any other run, through the items' tickets.
-template <typename T, int KC, bool STAGE, bool FAST, bool FASTA>
+template <typename T, int KC, bool STAGE, int FAST, bool FASTA>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
                                               int *tick_done, T *qs, T *bis, int32_t *err, int *rt_u, int *rt_t,
@@ -1269,12 +1270,12 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
 // WPS = waves per SIMD the kernel is built for: 8 (64 VGPRs) lets two 16-wave workgroups share a CU, 4 (128 VGPRs)
 // is one workgroup per CU without the register squeeze - 3-8% faster whenever the grid has no more stripes than
 // the GPU has CUs (measured: netflix 33.7 -> 32.3 ms, frozen 44.0 -> 40.7 ms), so both are built for k <= 128 fp32.
-template <typename T, int KC, bool STAGE, bool FAST, int WPS>
+template <typename T, int KC, bool STAGE, int FAST, int WPS>
 __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
     // the hot-item pipeline needs fp32 MFMA, k = 64 / 128 / 256, 128 registers and row buffers in LDS (lp.n_abuf > 0)
-    constexpr bool FASTA = FAST && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && WPS == 4;
+    constexpr bool FASTA = FAST == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && WPS == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
@@ -1450,19 +1451,20 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         }
         return MFSGD_OK;
     }
-    const bool fast = k == 64 * KC && z == nullptr && gv.user_unique;
+    // 0: general kernel; 1: k a multiple of 64, user-unique grid, no implicit term; 2: the same with the frozen term z
+    const int fast = k == 64 * KC && gv.user_unique ? (z == nullptr ? 1 : 2) : 0;
     hipDeviceProp_t prop;
     MF_HIP(hipGetDeviceProperties(&prop, G->device));
     // two workgroups per CU only pay when there are more stripes than CUs and two stripes fit the LDS of one
     constexpr bool can8 = WAVES_PER_SIMD(T, KC) == 8;
     // ... unless the grid has hot segments and their pipeline can run: it needs the 128-register build, and hot segments
     // that go through the tickets cost more than the second workgroup gains
-    const bool pipe = fast && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
+    const bool pipe = fast == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
                       lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs).n_abuf > 0;
     const bool wps8 = can8 && !pipe && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
-    auto kern = fast ? k_epoch_free<T, KC, STAGE, true, 4> : k_epoch_free<T, KC, STAGE, false, 4>;
+    auto kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 4> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 4> : k_epoch_free<T, KC, STAGE, 0, 4>;
     if constexpr (can8) {
-        if (wps8) kern = fast ? k_epoch_free<T, KC, STAGE, true, 8> : k_epoch_free<T, KC, STAGE, false, 8>;
+        if (wps8) kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 8> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 8> : k_epoch_free<T, KC, STAGE, 0, 8>;
     }
     // the hot-item pipeline (phase_a_gram): fp32, k = 64, 128 or 256, the 128-register build, and as many row buffers as
     // the LDS left by the stripe holds (at most G->hot_bufs); without a buffer the hot segments take the ticket path
