@@ -251,6 +251,7 @@ class ExplicitMF(Recommender):
                  hot_items=1,            # hot items (hot segments per block) a stripe may have where the pipeline runs (<= 8)
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
                  hot_min=64,             # ratings per block (on average) an item needs to become a hot item (two pipeline batches)
+                 pad_factors=True,       # throughput mode: device copies of P / Q / y get zero columns up to a multiple of 64
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -269,6 +270,7 @@ class ExplicitMF(Recommender):
         self.hot_items = int(hot_items)
         self.hot_cost = hot_cost
         self.hot_min = int(hot_min)
+        self.pad_factors = bool(pad_factors)
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -353,12 +355,25 @@ class ExplicitMF(Recommender):
         return test
 
     # ------------------------------------------------------------------ the GPU FPSGD path
+    def _device_k(self):
+        """Row width of the device copies of P / Q / y.  The free-block kernel has straight-line builds (exact waits, the
+        hot-item pipeline) for k = 64, 128, 192, 256 only; any other k runs the general build with lane guards and
+        optional loads, at about half the rate (netflix shape: k = 40 37.1 ms per epoch against 20.4 at k = 64, k = 100
+        45.3 against 23.7 at k = 128).  Zero columns stay zero under the update (p' = a p + alpha e q with p = q = 0) and
+        add zeros to every dot product, so in throughput mode the device rows are padded to the next multiple of 64 and
+        cut back when they return to the host: same factors, same errors."""
+        k = int(self.n_factors)
+        kd = -(-k // 64) * 64
+        if self.deterministic or not self.pad_factors or kd > 256:
+            return k
+        return kd
+
     def _pipeline_kernel(self):
         """The hot-item pipeline is worth its hot segments for fp32, k = 64 or 128, no implicit term.  The kernel also
         exists for k = 256 (csrc/epoch.hip, FASTA; parity-tested), but a batch's row buffer is 33 KB there, two fit
         next to a stripe, and two pipeline waves are slower than the tickets (netflix shape, k = 256: 74 ms per epoch
         against 56 ms), so the chooser does not ask for hot segments at k = 256."""
-        return (self.dtype != "float64" and self.n_factors in (64, 128) and (self.implicit or "frozen") == "none"
+        return (self.dtype != "float64" and self._device_k() in (64, 128) and (self.implicit or "frozen") == "none"
                 and self.hot_buffers > 0)
 
     def _pipeline_runs(self, Gr, Gc):
@@ -368,7 +383,7 @@ class ExplicitMF(Recommender):
         if not self._pipeline_kernel():
             return False
         ibp = -(-self.n_items // Gc)
-        return lds_bytes(ibp, Gr, self.n_factors, 4, min(2, self.hot_buffers)) <= 160 * 1024
+        return lds_bytes(ibp, Gr, self._device_k(), 4, min(2, self.hot_buffers)) <= 160 * 1024
 
     def _choose_grid(self):
         """Throughput grid.  A workgroup keeps its item stripe (rows of Q, b_i, tickets, run table) in LDS, and a CU has
@@ -382,7 +397,7 @@ class ExplicitMF(Recommender):
         if self.grid_shape is not None:
             Gr, Gc = self.grid_shape
         else:
-            k = self.n_factors
+            k = self._device_k()
             esz = 8 if self.dtype == "float64" else 4
             n = int(self._d_samples.shape[0])
             U, I = self.n_users, self.n_items
@@ -433,6 +448,10 @@ class ExplicitMF(Recommender):
     def _to_dev(self):
         td = "float64" if self.dtype == "float64" else "float32"
         self._dev = {n: _abi.to_device(getattr(self, n), td) for n in ("P", "Q", "b_u", "b_i")}
+        k, kd = int(self.n_factors), self._device_k()
+        self._kd = kd
+        pad = (lambda t: _abi.torch_mod().nn.functional.pad(t, (0, kd - k)).contiguous()) if kd != k else (lambda t: t)
+        self._dev["P"], self._dev["Q"] = pad(self._dev["P"]), pad(self._dev["Q"])
         self._dev["z"] = None
         imp = self.implicit or "frozen"
         if imp == "full":
@@ -441,17 +460,21 @@ class ExplicitMF(Recommender):
         if imp == "frozen":
             torch = _abi.torch_mod()
             rp, ci = self._ensure_csr()
-            dy = _abi.to_device(self.y, td)
+            dy = pad(_abi.to_device(self.y, td))
             z = torch.empty_like(self._dev["P"])
             fn = getattr(_abi.lib(), "mfsgd_hip_implicit_z_" + ("f64" if td == "float64" else "f32"))
-            _abi.check(fn(_abi.ptr(dy), _abi.ptr(rp), _abi.ptr(ci), self.n_users, self.n_factors, 0, _abi.ptr(z),
+            _abi.check(fn(_abi.ptr(dy), _abi.ptr(rp), _abi.ptr(ci), self.n_users, kd, 0, _abi.ptr(z),
                           _abi.stream_ptr()))
             self._dev["z"] = z
         return imp
 
     def _from_dev(self):
+        k = int(self.n_factors)
         for n in ("P", "Q", "b_u", "b_i"):
-            setattr(self, n, self._dev[n].double().cpu().numpy())
+            t = self._dev[n]
+            if n in ("P", "Q") and int(t.shape[1]) != k:
+                t = t[:, :k]                                    # the zero columns of _device_k stay on the device
+            setattr(self, n, t.double().cpu().numpy())
 
     def run_epochs(self, n_epochs, order_log=None):
         """`n_epochs` FPSGD epochs on the device-resident factors (no host traffic)."""
@@ -460,7 +483,7 @@ class ExplicitMF(Recommender):
         ct = _abi.ctype_of(kind)
         fn = getattr(_abi.lib(), "mfsgd_hip_epoch_" + kind)
         imp = 1 if d["z"] is not None else 0
-        _abi.check(fn(self._grid.handle, self.n_factors, _abi.ptr(d["P"]), _abi.ptr(d["Q"]), _abi.ptr(d["b_u"]),
+        _abi.check(fn(self._grid.handle, int(d["P"].shape[1]), _abi.ptr(d["P"]), _abi.ptr(d["Q"]), _abi.ptr(d["b_u"]),
                       _abi.ptr(d["b_i"]), ct(self.b), _abi.ptr(d["z"]), ct(self.alpha), ct(self.beta1),
                       ct(self.beta2), 0, imp, int(n_epochs), 0 if self.deterministic else 1,
                       int(self.seed + self.update_counter), int(self.n_workgroups), int(self.waves_per_wg),

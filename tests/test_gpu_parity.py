@@ -684,3 +684,54 @@ def test_als_step_rejects_bad_arguments(ra):
     rc = _abi.lib().mfsgd_hip_als_step_f32(_abi.ptr(lat), _abi.ptr(fix), _abi.ptr(rp2), _abi.ptr(ci2), _abi.ptr(v),
                                            2, 2, 2, 4, 0.1, None)
     assert rc != 0 and b"CSR" in _abi.lib().mfsgd_last_error()
+
+
+@pytest.mark.parametrize("mode", ["none", "frozen"])
+def test_zero_padded_factor_rows_train_to_the_same_factors(ra, orc, mode):
+    """ExplicitMF pads the device rows of P / Q / y with zero columns up to a multiple of 64 in throughput mode
+    (SGDRecommender._device_k: the straight-line kernel builds exist for those widths).  Zero columns stay zero and
+    change no dot product: with the SAME block order (fixed schedule) k = 40 and its padded k = 64 give the same
+    factors - and both match the oracle's plain sequential pass at k = 40."""
+    import torch
+    from recommender_amd import _abi
+    from recommender_amd.SGDRecommender import Grid
+    k, kd, U, I, n = 40, 64, 900, 400, 60000
+    rng = np.random.default_rng(40)
+    s = _synthetic(rng, U, I, n, lead=False)
+    ubp, ibp = 150, 80
+    gr = Grid(torch.from_numpy(s).cuda(), U, I, ubp, ibp, order=1, hot_segments=0)
+    P = rng.normal(scale=1 / k, size=(U, k)).astype(np.float32)
+    Q = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
+    y = rng.normal(scale=1 / k, size=(I, k)).astype(np.float32)
+    b = float(s[:, 2].mean())
+    rp, ci = orc.csr_from_coo(s, U)
+    z = orc.implicit_z(y, rp, ci, U) if mode == "frozen" else None
+    out = {}
+    for width in (k, kd):
+        pad = lambda a: np.ascontiguousarray(np.pad(a, ((0, 0), (0, width - k))))
+        dP, dQ = torch.from_numpy(pad(P)).cuda(), torch.from_numpy(pad(Q)).cuda()
+        dbu, dbi = torch.zeros(U, device="cuda"), torch.zeros(I, device="cuda")
+        dz = torch.from_numpy(pad(z)).cuda() if z is not None else None
+        _abi.check(_abi.lib().mfsgd_hip_epoch_f32(gr.handle, width, _abi.ptr(dP), _abi.ptr(dQ), _abi.ptr(dbu), _abi.ptr(dbi),
+                                                  b, _abi.ptr(dz), *HP, 0, 1 if z is not None else 0, 2, 0, 7, 0, 0, None, None))
+        gr.status()
+        out[width] = [t.cpu().numpy() for t in (dP, dQ, dbu, dbi)]
+    assert not out[kd][0][:, k:].any() and not out[kd][1][:, k:].any()          # the padding is still exactly zero
+    for a, b_ in zip(out[k], out[kd]):
+        ref = a if a.ndim == 1 else a[:, :k]
+        got = b_ if b_.ndim == 1 else b_[:, :k]
+        assert relerr(got, ref.astype(np.float64)) <= 1e-5
+    # and ExplicitMF hands unpadded rows back to the host
+    m = ra.ExplicitMF(n_threads=3, n_factors=k, implicit=mode, verbose=False)
+    m.load_samples_from_device(torch.from_numpy(s).cuda(), torch.from_numpy(s[:100]).cuda(), U, I)
+    m.balanced_renumber_samples()
+    m.build_grid()
+    m.init_params_device(3)
+    m._to_dev()
+    assert m._device_k() == kd and tuple(m._dev["P"].shape) == (U, kd) and tuple(m._dev["Q"].shape) == (I, kd)
+    e0 = m.device_errors()
+    m.run_epochs(2)
+    e1 = m.device_errors()
+    m._from_dev()
+    assert m.P.shape == (U, k) and m.Q.shape == (I, k) and e1[0] < e0[0]
+    assert not m._dev["P"][:, k:].any().item() and not m._dev["Q"][:, k:].any().item()
