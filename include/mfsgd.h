@@ -193,6 +193,11 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
  * take behind the stripe; 0 sends hot segments through the tickets too (same results up to rounding - the tests
  * replay both on the oracle's plain sequential kernel).  Takes effect from the next epoch call. */
 int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n);
+/* schedule 2 of mfsgd_hip_epoch_*: of the first `n` free user stripes a workgroup finds (1..64; default 3) it takes the one
+ * its item stripe has visited least often in this launch.  1 = any free stripe (passes blur most), 64 = practically the
+ * least visited free stripe (passes nearly in step).  The counterpart of the reference's "minimal update count among the
+ * free rows x free columns" (RayBlockScheduler.py:50-58); takes effect from the next epoch call. */
+int mfsgd_grid_set_pick_width(mfsgd_grid *g, int32_t n);
 /* Host-side helper for choosing a grid: bytes of LDS a free-block workgroup needs for item stripes of `ibp`
  * items, `Gr` user stripes, k factors of `elem_size` bytes (4 or 8) plus `hot_bufs` pipeline row buffers (fp32
  * only); -1 on bad arguments.  A CU has 160 KB.  Touches no device.  No counterpart in the reference (its grid is
@@ -211,7 +216,16 @@ int mfsgd_grid_col_times(const mfsgd_grid *g, int64_t *h_out, void *stream);
 /* schedule 0 = fixed: equals `iters` passes over the blocks in row-major order, each block walked in
  *               stored order (the deterministic fixed-block-order mode);
  * schedule 1 = free-block: workgroups pull column stripes (heaviest first) and lock free row stripes
- *               on the GPU; every block is done exactly once per epoch, conflicting blocks never overlap.
+ *               on the GPU; every block is done exactly once per epoch (one launch per epoch), conflicting blocks
+ *               never overlap;
+ * schedule 2 = free-block with the passes OVERLAPPED as the reference's scheduler overlaps them: BlockScheduler runs its
+ *               `iters` passes in one session and hands out "a block of minimal update count among the free rows x free
+ *               columns" (RayBlockScheduler.py:50-58) - with n_threads + 1 stripes a worker sees one or two of each, so a
+ *               fifth of the blocks get a visit more than a full pass late and others their next visit early
+ *               (profiles/r3_pass_overlap.txt).  Here: all `iters` passes in ONE launch, every workgroup keeps its item
+ *               stripe throughout and takes, of the first few free user stripes it finds (mfsgd_grid_set_pick_width), the one
+ *               it has visited least; every block still gets exactly `iters` visits and conflicting blocks never
+ *               overlap.  Needs a workgroup per non-empty item stripe (Gc <= CUs); other grids run it as schedule 1.
  * order_log (nullable, int32 [iters*Gr*Gc][2], device): blocks in the order they were issued.
  * n_workgroups / waves_per_wg: 0 = auto.  implicit in {0,1} (z required for 1). */
 int mfsgd_hip_epoch_f32(mfsgd_grid *g, int32_t k, float *P, float *Q, float *b_u, float *b_i, float b, const float *z,

@@ -196,6 +196,10 @@ class Grid:
         0..8; 0 sends the hot segments through the item tickets like every other rating (same results up to rounding)."""
         _abi.check(_abi.lib().mfsgd_grid_set_hot_buffers(self.handle, int(n)))
 
+    def set_pick_width(self, n):
+        """mfsgd_grid_set_pick_width: schedule 2 takes the least visited of the first `n` free user stripes."""
+        _abi.check(_abi.lib().mfsgd_grid_set_pick_width(self.handle, int(n)))
+
     def col_hot(self):
         """[Gc][MFSGD_MAX_HOT]: per item stripe the global ids of its hot items, most rated first (item s's ratings form
         hot segment s of the stripe's blocks); -1 = none."""
@@ -252,6 +256,9 @@ class ExplicitMF(Recommender):
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
                  hot_min=64,             # ratings per block (on average) an item needs to become a hot item (two pipeline batches)
                  pad_factors=True,       # throughput mode: device copies of P / Q / y get zero columns up to a multiple of 64
+                 pass_barrier=False,     # False: the passes of one run_epochs call overlap like the reference's scheduler lets
+                                         # them (schedule 2: one launch, least-visited-of-two); True: a launch per pass
+                 pick_width=None,        # schedule 2: free user stripes among which the least visited is taken (None: library default)
                  n_workgroups=0, waves_per_wg=0, seed=0, verbose=True):
         self.n_threads = n_threads
         self.n_factors = n_factors
@@ -271,6 +278,9 @@ class ExplicitMF(Recommender):
         self.hot_cost = hot_cost
         self.hot_min = int(hot_min)
         self.pad_factors = bool(pad_factors)
+        self.pass_barrier = bool(pass_barrier)
+        self.pick_width = pick_width
+        self._launches = 0
         self.n_workgroups, self.waves_per_wg, self.seed, self.verbose = n_workgroups, waves_per_wg, seed, verbose
         self.history = []            # (epoch, train_rmse, test_rmse, alpha) at every bold-driver checkpoint
         self.row_perm = self.col_perm = None
@@ -443,6 +453,8 @@ class ExplicitMF(Recommender):
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)
         if self.hot_buffers != 8:
             self._grid.set_hot_buffers(self.hot_buffers)
+        if self.pick_width is not None:
+            self._grid.set_pick_width(self.pick_width)
         return self._grid
 
     def _to_dev(self):
@@ -485,9 +497,10 @@ class ExplicitMF(Recommender):
         imp = 1 if d["z"] is not None else 0
         _abi.check(fn(self._grid.handle, int(d["P"].shape[1]), _abi.ptr(d["P"]), _abi.ptr(d["Q"]), _abi.ptr(d["b_u"]),
                       _abi.ptr(d["b_i"]), ct(self.b), _abi.ptr(d["z"]), ct(self.alpha), ct(self.beta1),
-                      ct(self.beta2), 0, imp, int(n_epochs), 0 if self.deterministic else 1,
-                      int(self.seed + self.update_counter), int(self.n_workgroups), int(self.waves_per_wg),
-                      _abi.ptr(order_log), _abi.stream_ptr()))
+                      ct(self.beta2), 0, imp, int(n_epochs), 0 if self.deterministic else (1 if self.pass_barrier else 2),
+                      int(self.seed + self.update_counter + 7919 * self._launches), int(self.n_workgroups),
+                      int(self.waves_per_wg), _abi.ptr(order_log), _abi.stream_ptr()))
+        self._launches += 1
 
     def device_errors(self):
         self._grid.status()

@@ -45,6 +45,7 @@ struct DevBuf {
 using mfprep::DevBuf;
 
 constexpr int PA_MAX_BUFS_DEFAULT = 8;
+constexpr int PICK_WIDTH_DEFAULT = 3, PICK_WIDTH_MAX = 64;   // 3: held-out RMSE closest to the reference scheduler's band on both full-size shapes (profiles/r3_rmse_parity.txt)
 constexpr int MAXSEG = MFSGD_MAX_HOT;   // hot segments per block
 // classes of a rating inside its block: hot segment 0 .. MAXSEG-1, then the rest - first the ratings of users WITHOUT a
 // rating in a hot segment of this block (class MAXSEG: nothing to wait for while the pipeline walks the segments), then
@@ -61,6 +62,7 @@ struct mfsgd_grid {
     int32_t *blk_free_runs = nullptr;  // [Gr*Gc] runs of class MAXSEG: users of the block without a rating in a hot segment
     int32_t max_block_runs = 0;
     int32_t hot_bufs = PA_MAX_BUFS_DEFAULT;   // LDS row buffers the hot-item pipeline may take (0: ticket path only)
+    int32_t pick_width = PICK_WIDTH_DEFAULT;  // schedule 2: free user stripes among which the least visited one is taken
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -85,12 +87,15 @@ struct SchedView {
     int32_t *row_lock, *counters, *order_log;
     int32_t log_base;  // epoch * Gr * Gc
     uint32_t seed;
-    int32_t *err;      // sticky error word: 1 = ticket wait ran out, 2 = row-lock search ran out
+    int32_t *err;      // sticky error word: 1 = ticket wait ran out, 2 = row-lock search ran out, 4 = a wait of the hot-item pipeline
     long long *col_clock;
+    int32_t passes;    // visits every block gets in THIS launch (schedule 2: > 1, no barrier between the passes)
+    int32_t pick;      // schedule 2: the least visited of the first `pick` free-looking user stripes is taken
 };
 
 constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
 constexpr int SPIN_LOCK_SWEEPS = 1 << 20;
+constexpr int MAX_PASSES_PER_LAUNCH = 200;   // visit counts live in one byte per user stripe (row_done in k_epoch_free)
 #ifndef TICKET_NAP
 #define TICKET_NAP 3   // s_sleep units (64 clocks) a waiter sleeps per hand-off in front of it
 #endif
@@ -824,7 +829,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
         if (MULTI && seg > 0) {   // the earlier segments must be done for this batch's users before their rows are loaded
             const int32_t last_user = __builtin_amdgcn_readlane(uj, PA_B - 1);
             for (int spins = 0; hot_frontier(ctl, seg) < last_user; ++spins) {
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -872,7 +877,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
         // 4. the wave's turn
         for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(tok, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
-            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order; the LDS serves a wave in issue order
@@ -967,7 +972,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(front, __ATOMIC_RELAXED,
                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) != m; ++spins) {
-            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         {
@@ -1117,7 +1122,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
                     const int32_t u = w & 0x7fffffff;
                     for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(
                                             &ctl[CTL_FMIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < u; ++spins) {
-                        if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 1); break; }
+                        if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1286,6 +1291,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
     // The scheduler runs on wave 0 with all 64 lanes executing the same (wave-uniform) code; the branch that
     // selects wave 0 is scalar, and nothing inside is predicated per lane (sink_ptr).
     const bool sched_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const int32_t passes = s.passes;   // visits per block in this launch (1 unless schedule 2)
 #ifdef MFSGD_PROF
     unsigned long long pf[PF_SLOTS] = {};
     PF_T(k0);
@@ -1314,15 +1320,14 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
             rowrun[4 * r + 1] = hi;
             rowrun[4 * r + 2] = g.blk_hot_cnt[r * g.Gc + c];
             rowrun[4 * r + 3] = g.blk_free_runs[r * g.Gc + c];
-            row_done[r] = empty ? 1 : 0;
-            mine += empty ? 0 : 1;
+            row_done[r] = empty ? passes : 0;    // visits of block (r, c) so far in this launch
+            mine += empty ? 0 : passes;
         }
         atomicAdd(&ctl[CTL_REMAIN], mine);
         if (tid < MAXSEG) ctl[CTL_HOT + tid] = g.col_hot[(size_t)c * MAXSEG + tid];   // the stripe's hot items
         stripe_load<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         __syncthreads();
         int32_t held = -1;   // scheduler wave: the row of the block just finished, released AFTER the next one is found
-        int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + s.seed) % (uint32_t)g.Gr);
 
         for (;;) {
             if (sched_wave) {
@@ -1339,37 +1344,59 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                 };
                 for (int sweeps = 0; remain > 0 && found < 0; ++sweeps) {
                     if (sweeps >= SPIN_LOCK_SWEEPS) { atomicOr(s.err, 2); break; }
-                    // 64 rows per step: every lane looks at one row of the rotation that starts at `pos`
-                    for (int32_t base = 0; base < g.Gr && found < 0; base += 64) {
+                    // The search starts at a pseudo-random row every time (workgroups that look at the same stretch see the
+                    // same free rows and would all race for the first), 64 rows per step: every lane looks at one row
+                    // of the rotation that starts at `pos`
+                    const int32_t pos = (int32_t)(mix32((uint32_t)c * 0x9E3779B9u + (uint32_t)(remain + sweeps) * 0x85EBCA6Bu + s.seed) %
+                                                  (uint32_t)g.Gr);
+                    // peek at the lock words with one coalesced agent-scope load per 64 rows (two cache lines from L2; as
+                    // a vector atomic this was 64 read-modify-writes on those lines per peek, and with short blocks the
+                    // lock search grew to 40% of the epoch) and collect the first free-looking rows of the rotation.
+                    // One pass per launch: the first one is taken.  Several passes in one launch (schedule 2): of the
+                    // FIRST TWO free-looking rows the one this column has visited less often goes first.  That is the
+                    // reference's rule - "a block of minimal update count among the free rows x free columns",
+                    // RayBlockScheduler.py:50-58, where with n_threads + 1 stripes a worker sees one or two free rows and
+                    // columns - and like there a block can get its second visit while others still wait for their
+                    // first: the passes overlap (profiles/r3_pass_overlap.txt compares the two schedulers' visit times).
+                    const int want = passes > 1 ? s.pick : 1;
+                    int32_t r1 = -1, r2 = -1, v1 = 0x7fffffff, v2 = 0x7fffffff, got = 0;   // least and second least visited
+                    for (int32_t base = 0; base < g.Gr && got < want; base += 64) {
                         int32_t r = pos + base + lane;
                         while (r >= g.Gr) r -= g.Gr;
-                        bool cand = base + lane < g.Gr && !row_done[r];
+                        const int32_t visits = row_done[r];
+                        bool cand = base + lane < g.Gr && visits < passes;
                         if (__ballot(cand) == 0) continue;
-                        // peek at the 64 lock words with one coalesced agent-scope load (two cache lines from L2; as
-                        // a vector atomic this was 64 read-modify-writes on those lines per peek, and with short
-                        // blocks the lock search grew to 40% of the epoch), then try only rows that look free,
-                        // starting at a pseudo-random one: workgroups that look at the same stretch see the same
-                        // free rows and would all race for the lowest
                         const int32_t lockv = __hip_atomic_load(&s.row_lock[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         cand = cand && lockv == 0;
                         unsigned long long mask = __ballot(cand);
-                        int32_t skip = (int32_t)(mix32((uint32_t)(c * 977 + remain) + s.seed) %
-                                                 (uint32_t)(__builtin_popcountll(mask) | 1));
-                        unsigned long long low = 0;
-                        while (skip-- > 0 && (mask & (mask - 1)) != 0) { low |= mask & (0 - mask); mask &= mask - 1; }
-                        while ((mask | low) != 0 && found < 0) {
-                            if (mask == 0) { mask = low; low = 0; }
+                        while (mask != 0 && got < want) {
                             const int l = __builtin_ctzll(mask);
                             mask &= mask - 1;
-                            const int32_t rc = __builtin_amdgcn_readlane(r, l);
-                            // one real CAS (lane 0); the other lanes hit their own sink words
-                            int32_t expect = 0;
-                            int32_t *w = sink_ptr(&s.row_lock[rc], ctl, lane);
-                            if (lane != 0) expect = 0x7fffffff;   // value select, not control flow
-                            __hip_atomic_compare_exchange_strong(w, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
-                            if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;   // unchanged <=> swapped
+                            ++got;
+                            const int32_t rc = __builtin_amdgcn_readlane(r, l), vc = __builtin_amdgcn_readlane(visits, l);
+                            if (vc < v1) { r2 = r1; v2 = v1; r1 = rc; v1 = vc; }      // ties keep the rotation's order
+                            else if (vc < v2) { r2 = rc; v2 = vc; }
                         }
+                    }
+#ifdef MFSGD_SCHED_DBG
+                    atomicAdd(sink_ptr(&s.counters[2], ctl, lane), 1);                       // sweeps
+                    if (r1 < 0) atomicAdd(sink_ptr(&s.counters[3], ctl, lane), 1);           // ... that saw no candidate
+                    if (r1 >= 0 && r2 < 0) atomicAdd(sink_ptr(&s.counters[4], ctl, lane), 1);  // ... exactly one
+                    if (r2 >= 0 && v2 != v1) atomicAdd(sink_ptr(&s.counters[6], ctl, lane), 1);  // two with different counts
+#endif
+                    for (int attempt = 0; attempt < 2 && found < 0; ++attempt) {
+                        const int32_t rc = attempt == 0 ? r1 : r2;
+                        if (rc < 0) break;
+                        // one real CAS (lane 0); the other lanes hit their own sink words
+                        int32_t expect = 0;
+                        int32_t *w = sink_ptr(&s.row_lock[rc], ctl, lane);
+                        if (lane != 0) expect = 0x7fffffff;   // value select, not control flow
+                        __hip_atomic_compare_exchange_strong(w, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_readlane(expect, 0) == 0) found = rc;   // unchanged <=> swapped
+#ifdef MFSGD_SCHED_DBG
+                        else atomicAdd(sink_ptr(&s.counters[5], ctl, lane), 1);             // CAS lost
+#endif
                     }
                     if (found < 0) {
                         release();   // never wait for a row while holding one
@@ -1377,8 +1404,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                     }
                 }
                 if (found >= 0) {
-                    row_done[found] = 1;
-                    pos = found + 1 == g.Gr ? 0 : found + 1;
+                    row_done[found] = (unsigned char)(row_done[found] + 1);   // every lane, same value
                     ctl[CTL_REMAIN] = remain - 1;
                     // acquire: drop this CU's L1 so that the previous holder's P rows are re-read
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1431,7 +1457,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
                   T beta2, int variant, int k, int iters, int schedule, uint64_t seed, int n_wg, int waves,
                   int32_t *order_log, hipStream_t st)
 {
-    const bool dynamic = schedule == 1;
+    const bool dynamic = schedule >= 1;
     LdsPlan<T> lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic);
     if (waves <= 0) waves = 16;
     if (waves > 16) waves = 16;
@@ -1441,7 +1467,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         auto kern = k_epoch_fixed<T, KC, STAGE>;
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
         for (int it = 0; it < iters; ++it) {
-            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8, G->col_clock};
+            SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)seed, G->counters + 8, G->col_clock, 1, 1};
             for (int d = 0; d <= gv.Gr + gv.Gc - 2; ++d) {
                 const int r0 = std::max(0, d - (gv.Gc - 1)), r1 = std::min(gv.Gr - 1, d);
                 hipLaunchKernelGGL(kern, dim3(r1 - r0 + 1), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z,
@@ -1475,11 +1501,19 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
         per_cu = std::max(1, std::min(per_cu, std::max(1, (wps8 ? 32 : 16) / waves)));
         n_wg = prop.multiProcessorCount * per_cu;
     }
+    // schedule 2: all `iters` passes in ONE launch, no barrier between them - every workgroup keeps its item stripe and
+    // visits each user stripe `iters` times, least visited of two first (k_epoch_free) - when every non-empty stripe has a
+    // workgroup of its own; with more stripes than workgroups a tenure of several passes would give a stripe all its
+    // visits in one burst, so such grids run pass by pass like schedule 1
+    const bool all_resident = G->n_cols_nonempty <= n_wg;
     n_wg = std::max(1, std::min(n_wg, G->n_cols_nonempty > 0 ? G->n_cols_nonempty : 1));
-    for (int it = 0; it < iters; ++it) {
+    const int per_launch = schedule == 2 && all_resident ? MAX_PASSES_PER_LAUNCH : 1;
+    for (int it = 0; it < iters; it += per_launch) {
+        const int passes = std::min(per_launch, iters - it);
         MF_HIP(hipMemsetAsync(G->counters, 0, 32, st));
         MF_HIP(hipMemsetAsync(G->row_lock, 0, sizeof(int32_t) * (((size_t)gv.Gr + 3) & ~(size_t)3), st));
-        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8, G->col_clock};
+        SchedView s{G->row_lock, G->counters, order_log, (int32_t)(it * nb), (uint32_t)(seed + 0x9E37u * it), G->counters + 8, G->col_clock,
+                    passes, G->pick_width};
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(threads), lp.total, st, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2,
                            variant, k, lp, s);
         MF_LAUNCH_CHECK();
@@ -1496,7 +1530,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     MF_ARG(k >= 1 && k <= 256, "epoch: k=%d outside [1,256]", k);
     MF_ARG(variant == 0 || variant == 1, "epoch: variant must be 0 or 1");
     MF_ARG(implicit == 0 || (implicit == 1 && z), "epoch: implicit must be 0, or 1 with z (2 needs the serial pass)");
-    MF_ARG(schedule == 0 || schedule == 1, "epoch: schedule must be 0 (fixed) or 1 (free-block)");
+    MF_ARG(schedule >= 0 && schedule <= 2, "epoch: schedule must be 0 (fixed), 1 (free-block) or 2 (free-block, passes overlapped)");
     MF_ARG(iters >= 0, "epoch: iters < 0");
     if (implicit == 0) z = nullptr;
     const mfsgd_grid_info &in = G->info;
@@ -1504,7 +1538,7 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
     GridView gv{G->blk_run_ptr, G->run_start, G->run_user, G->item, G->tick, G->val, G->col_order,
                 in.Gr, in.Gc, in.ubp, in.ibp, in.user_unique, G->n_cols_nonempty, in.n_users, in.n_items,
                 (int32_t)in.n_runs, G->col_hot, G->blk_hot_cnt, G->blk_seg_cnt, G->blk_free_runs};
-    const bool dynamic = schedule == 1;
+    const bool dynamic = schedule >= 1;
     const size_t cap = LDS_CAP;
     const bool stage = lds_plan<T>(in.ibp, in.Gr, k, true, dynamic).total <= cap;
     if (!stage && lds_plan<T>(in.ibp, in.Gr, k, false, dynamic).total > cap) {
@@ -1549,10 +1583,19 @@ int mfsgd_grid_status(mfsgd_grid *g, void *stream)
     hipStream_t st = as_stream(stream);
     MF_HIP(hipMemcpyAsync(&h, g->counters + 8, 4, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
+#ifdef MFSGD_SCHED_DBG
+    {
+        int32_t c[8];
+        MF_HIP(hipMemcpy(c, g->counters, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "sched dbg (last launch): blocks %d, sweeps %d, no candidate %d, one candidate %d, CAS lost %d, two with different counts %d\n",
+                c[1], c[2], c[3], c[4], c[5], c[6]);
+    }
+#endif
     if (h) {
         MF_HIP(hipMemsetAsync(g->counters + 8, 0, 4, st));
-        mfsgd_set_error("epoch kernel gave up waiting (%s%s): results of that run are invalid",
-                        (h & 1) ? "item ticket " : "", (h & 2) ? "row lock" : "");
+        mfsgd_set_error("epoch kernel gave up waiting (%s%s%s): results of that run are invalid",
+                        (h & 1) ? "item ticket " : "", (h & 2) ? "row lock " : "",
+                        (h & 4) ? "hot-item pipeline: user frontier / turn / publish order" : "");
         return MFSGD_ERR_GRID;
     }
     return MFSGD_OK;
@@ -1572,6 +1615,14 @@ int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n)
     MF_ARG(g, "grid_set_hot_buffers: null grid");
     MF_ARG(n >= 0 && n <= PA_MAX_BUFS, "grid_set_hot_buffers: n=%d outside [0,%d]", n, PA_MAX_BUFS);
     g->hot_bufs = n;
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_set_pick_width(mfsgd_grid *g, int32_t n)
+{
+    MF_ARG(g, "grid_set_pick_width: null grid");
+    MF_ARG(n >= 1 && n <= PICK_WIDTH_MAX, "grid_set_pick_width: n=%d outside [1,%d]", n, PICK_WIDTH_MAX);
+    g->pick_width = n;
     return MFSGD_OK;
 }
 

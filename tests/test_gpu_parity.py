@@ -280,7 +280,7 @@ def _synthetic(rng, U, I, n, lead=False):
 
 
 def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1, dt=np.float32, tol=1e-4, variant=0,
-                 lead=None, iters=2, hot=None):
+                 lead=None, iters=2, hot=None, pick=None):
     """Run `iters` epochs on the GPU with the block order logged, replay that order block by block through the CPU
     oracle's plain sequential kernel (orc_sgd) in the grid's stored order, compare the factors."""
     import torch
@@ -296,6 +296,8 @@ def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1,
     gr = Grid(d_s, U, I, ubp, ibp, order=1, hot_segments=hot)
     assert gr.info.user_unique == 1 and gr.info.n == len(s) and (gr.info.Gr, gr.info.Gc) == (Gr, Gc)
     gr.set_hot_buffers(hot_bufs)
+    if pick is not None:
+        gr.set_pick_width(pick)
     col_hot = gr.col_hot()
     assert gr.info.n_hot_stripes == (col_hot[:, 0] >= 0).sum() and gr.info.n_hot_items == (col_hot >= 0).sum()
     assert all(h < 0 or h // ibp == c for c, row in enumerate(col_hot) for h in row)
@@ -321,14 +323,23 @@ def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1,
     assert int(hot.sum()) == gr.info.n_hot
     ptr = np.searchsorted(ks, np.arange(Gr * Gc + 1))
     nonempty = {(b_ // Gc, b_ % Gc) for b_ in range(Gr * Gc) if ptr[b_ + 1] > ptr[b_]}
-    for e in range(iters):
+    if schedule == 2:       # one launch, passes overlapped: every block `iters` times in all, in whatever order
+        from collections import Counter
+        visits = Counter(tuple(x) for x in log.reshape(-1, 2) if x[0] >= 0)
+        assert set(visits) == nonempty and set(visits.values()) == {iters}
+        first = [tuple(x) for x in log.reshape(-1, 2)[:len(nonempty)] if x[0] >= 0]
+        overlapped = len(set(first)) < len(first)       # a block came back before every block had its first visit
+        log = log.reshape(1, -1, 2)
+    for e in range(log.shape[0]):
         issued = [tuple(x) for x in log[e] if x[0] >= 0]
-        assert len(issued) == len(set(issued)) and set(issued) == nonempty
+        assert schedule == 2 or (len(issued) == len(set(issued)) and set(issued) == nonempty)
         for r, c in issued:
             blk = ss[ptr[r * Gc + c]:ptr[r * Gc + c + 1]]
             orc.sgd(P, Q, bu, bi, b, None, blk, None, None, *HP, variant=variant, implicit=1 if z is not None else 0, z=z)
     for name, dev, ref in (("P", dP, P), ("Q", dQ, Q), ("b_u", dbu, bu), ("b_i", dbi, bi)):
         assert relerr(dev.cpu().numpy(), ref.astype(np.float64)) <= tol, name
+    if schedule == 2:
+        return gr.info, overlapped
     return gr.info
 
 
@@ -344,6 +355,28 @@ def test_free_block_schedule_replays_on_oracle(ra, orc, k, U, I, n, grid, waves,
     """The on-GPU scheduler may issue blocks in any conflict-free order; its log, replayed block by block
     through the CPU oracle, must reproduce the GPU factors (fp32 tolerance), every block exactly once/epoch."""
     _replay_case(ra, orc, k, U, I, n, grid, waves, mode)
+
+
+def test_overlapped_passes_replay_on_oracle(ra, orc):
+    """schedule 2: all passes in one launch, no barrier between them, the least visited of the first few free user
+    stripes first (the reference's scheduler hands out "a block of minimal update count among the free rows x free
+    columns" in ONE session over all passes, RayBlockScheduler.py:35-68, :185).  Whatever the order, every block gets
+    exactly `iters` visits, conflicting blocks never overlap - so the logged order, replayed visit by visit on the
+    oracle's plain sequential kernel, reproduces the GPU factors - and the passes do overlap."""
+    seen_overlap = False
+    for kw in (dict(k=32, U=500, I=300, n=30000, grid=(8, 6), waves=4, mode="none", iters=3),
+               dict(k=128, U=3000, I=900, n=200000, grid=(64, 16), waves=8, mode="none", iters=4),          # pipeline
+               dict(k=128, U=3000, I=900, n=200000, grid=(64, 16), waves=8, mode="none", iters=3, hot_bufs=0),
+               dict(k=64, U=2000, I=5000, n=150000, grid=(32, 32), waves=16, mode="frozen", iters=3),
+               dict(k=64, U=2000, I=5000, n=150000, grid=(32, 32), waves=16, mode="none", iters=5, pick=1),
+               dict(k=64, U=2000, I=5000, n=150000, grid=(32, 32), waves=16, mode="none", iters=3, pick=64),
+               dict(k=200, U=700, I=400, n=40000, grid=(16, 8), waves=8, mode="none", iters=3, variant=1),
+               dict(k=64, U=2000, I=5000, n=150000, grid=(32, 32), waves=16, mode="none", iters=3, dt=np.float64, tol=1e-9)):
+        kw = dict(kw)
+        _, overlapped = _replay_case(ra, orc, kw.pop("k"), kw.pop("U"), kw.pop("I"), kw.pop("n"), kw.pop("grid"),
+                                     kw.pop("waves"), kw.pop("mode"), schedule=2, **kw)
+        seen_overlap = seen_overlap or overlapped
+    assert seen_overlap
 
 
 @pytest.mark.parametrize("hot_bufs", [0, 1, 8])
