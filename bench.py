@@ -29,6 +29,20 @@ def bytes_per_update(k, implicit):
     return 16 * k + 28 + (4 * k if implicit == "frozen" else 0)
 
 
+def kernel_source_hash():
+    """Identifies the build a PMC record in profiles/traffic.json belongs to: sha256 over the kernel sources (the GPU box
+    has no .git).  profiles/collect_traffic.py stores the same hash with every record it writes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "recommender_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "recommender_amd", "csrc", "*.h")) +
+                       [os.path.join(ROOT, "include", "mfsgd.h")]):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -77,7 +91,7 @@ def cpu_baseline(torch, m, k, implicit):
                       f"{legs['f64']['seconds']:.2f} s (value), fp32 {legs['f32']['seconds']:.2f} s (value_f32)"}
 
 
-def run_leg(args, torch, ra, data, k, hot_buffers):
+def run_leg(args, torch, ra, data, k, hot_buffers, renumber=None):
     """One measured configuration: prep (renumber + grid), warm-up epochs, `steps` timed epochs."""
     import numpy as np
     train, test, U, I = data
@@ -90,7 +104,7 @@ def run_leg(args, torch, ra, data, k, hot_buffers):
     m.load_samples_from_device(train.clone(), test.clone(), U, I)      # renumbering rewrites the ids in place
     np.random.seed(args.seed % (2 ** 31))
     t0 = time.perf_counter()
-    if args.renumber == "balanced":
+    if (renumber or args.renumber) == "balanced":
         m.balanced_renumber_samples()            # D2 with a load-balancing permutation
     else:
         m.random_renumber_samples()              # D2 exactly as the reference (random shuffle)
@@ -132,6 +146,9 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--renumber", default="balanced", choices=["balanced", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-random-leg", action="store_true",
+                    help="also time the reference's own D2 (random shuffle of the ids, SGDRecommender.py:228-232) instead of "
+                         "the load-balancing permutation: same kernel, stripes of unequal weight")
     ap.add_argument("--with-tickets-leg", action="store_true",
                     help="also time the same grid with the hot segments on the ticket path (hot_buffers 0)")
     ap.add_argument("--seed", type=int, default=BASE_SEED)
@@ -140,7 +157,7 @@ def main():
     ap.add_argument("--hot-items", type=int, default=-1,
                     help="hot items (hot segments per block) a stripe may have where the pipeline runs (default: the library's)")
     ap.add_argument("--hot-min", type=int, default=-1,
-                    help="ratings per block an item needs to become a hot item (default: the model's, 32)")
+                    help="ratings per block an item needs to become a hot item (default: the model's, 64)")
     ap.add_argument("--hot-buffers", type=int, default=8,
                     help="LDS row buffers of the hot-item pipeline (mfsgd_grid_set_hot_buffers); 0 = every rating "
                          "through the item tickets.  Either way a block is walked sequentially in stored order")
@@ -178,19 +195,30 @@ def main():
     except Exception:
         traffic_db = {}
 
+    src_hash = kernel_source_hash()
+
     def summarize(leg):
         g = leg["grid"].info
         avg_s = sum(leg["kern_ms"]) / len(leg["kern_ms"]) / 1e3
         key = f"{args.workload}/k{k}/{args.implicit}/{g.Gr}x{g.Gc}/hot{leg['hot_buffers']}"
-        traffic = traffic_db.get(key, {}).get("traffic_bytes")
+        rec = traffic_db.get(key, {})
+        # PMC bytes are only quoted for the build they were measured on (profiles/collect_traffic.py stores the hash)
+        traffic = rec.get("traffic_bytes") if rec.get("source_hash") == src_hash else None
         achieved = B * leg["n_train"] / avg_s
         return {"value": args.steps * leg["n_train"] / leg["wall"], "ms_per_step": leg["wall"] / args.steps * 1e3,
                 "grid": [g.Gr, g.Gc], "hot_buffers": leg["hot_buffers"], "avg_kernel_s": avg_s,
                 "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK, "traffic": traffic, "bytes_per_update": B,
-                             # what really crosses HBM (the Q stripe lives in LDS): PMC bytes / launch time / peak
-                             "traffic_frac": (traffic / avg_s / HBM_PEAK) if traffic else None,
-                             "limiter": "VALU issue + LDS ticket hand-offs (DESIGN.md section 4), not HBM bandwidth",
+                             # `achieved` / `frac` price the ALGORITHMIC bytes (16k + 28 per update) - the
+                             # contract's definition; the kernel moves about a third of them (the Q stripe lives in LDS, a
+                             # run reads and writes its P row once), so the fraction of the HBM peak it really uses is
+                             # compulsory_frac = PMC bytes / launch time / peak (null without a PMC record of THIS build)
+                             "achieved_kind": "algorithmic bytes per launch / launch time (not measured traffic)",
+                             "compulsory_frac": (traffic / avg_s / HBM_PEAK) if traffic else None,
+                             "traffic_source": (f"profiles/traffic.json[{key}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                f"source_hash {src_hash})") if traffic else None,
+                             "source_hash": src_hash,
+                             "limiter": "latency of one rating on one wave + LDS ticket hand-offs (DESIGN.md section 4), not HBM bandwidth",
                              "hot_segment_ratings": int(g.n_hot),
                              "kernel": "k_epoch_free", "kernel_ms": leg["kern_ms"]},
                 "rmse": {"train_before": leg["rmse0"][0], "test_before": leg["rmse0"][1],
@@ -212,6 +240,14 @@ def main():
         "roofline": head["roofline"], "rmse": head["rmse"],
     }
     cpu_m = leg["m"]
+    if args.with_random_leg and args.renumber == "balanced":
+        leg3 = run_leg(args, torch, ra, (train, test, U, I), k, args.hot_buffers, renumber="random")
+        s3 = summarize(leg3)
+        out["random_renumbering"] = {"value": s3["value"], "unit": "updates/s", "ms_per_step": s3["ms_per_step"],
+                                     "grid": s3["grid"], "frac": s3["roofline"]["frac"], "kernel_ms": s3["roofline"]["kernel_ms"],
+                                     "rmse": s3["rmse"],
+                                     "note": "the reference's D2 (SGDRecommender.py:228-232) instead of the load-balancing permutation"}
+        del leg3
     if args.with_tickets_leg and args.hot_buffers:
         leg2 = run_leg(args, torch, ra, (train, test, U, I), k, 0)
         s2 = summarize(leg2)

@@ -78,7 +78,11 @@ int mfsgd_hip_rmse_f64(const double *P, const double *Q, const double *b_u, cons
  * caller's.  Same kernels, same fixed reduction order: *d_sse is bit-identical to mfsgd_hip_rmse_f32's.
  * Limits: n <= MFSGD_RMSE_NOALLOC_MAX_N ratings per call, k <= MFSGD_RMSE_NOALLOC_MAX_K; beyond them the call
  * fails with MFSGD_ERR_ARG and touches nothing.  Every call on one GPU shares that GPU's array: calls that
- * overlap on one GPU (two streams, two threads) race - serialise them.  Asynchronous on `stream`. */
+ * overlap on one GPU (two streams, two threads) race - serialise them.  Asynchronous on `stream`.
+ * Set-up: the array's address is resolved once per GPU (hipGetSymbolAddress, which may load the code object) by
+ * mfsgd_device_check() called with that GPU current - or, failing that, by the first call of this entry on the GPU,
+ * which is then NOT capture-safe: call mfsgd_device_check() once per GPU outside any capture.  The scratch used is
+ * the CURRENT device's: P and d_sse must live on it, else MFSGD_ERR_ARG. */
 #define MFSGD_RMSE_NOALLOC_MAX_N ((int64_t)2147483647)
 #define MFSGD_RMSE_NOALLOC_MAX_K 4096
 int mfsgd_hip_rmse_noalloc_f32(const float *P, const float *Q, const float *b_u, const float *b_i, float b,
@@ -170,7 +174,10 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
  * which every wave waits for the same item).  So a caller that knows the pipeline will run passes (1, 64) - ExplicitMF.build_grid does -
  * and one that knows it will not - k other than 64 / 128 / 256, fp64, an implicit term, item stripes that leave no
  * LDS for its row buffers - passes (0, 0).  mfsgd_grid_create is one hot item per stripe of any length, if it
- * carries >= 1/16 of the stripe's ratings. */
+ * carries >= 1/16 of the stripe's ratings - a default for callers that will run fp32, k = 64 / 128 / 256 without an
+ * implicit term on stripes that leave LDS for at least two row buffers (the launch then walks the segments with the
+ * pipeline and runs one workgroup per CU); every other caller should say (0, 0) here: its hot segments would go
+ * through the tickets, which is slower than no hot segments (ML-25M shape: 13.0 against 11.8 ms per epoch). */
 int mfsgd_grid_create_opt(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                           int32_t ubp, int32_t ibp, int32_t order, int32_t hot_items, int32_t hot_min_per_block,
                           void *stream, mfsgd_grid **out);
@@ -185,7 +192,7 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
  * memory system, bounds their stripes.  A stripe's most rated item becomes its HOT item when it carries >= 1/16 of
  * the stripe's ratings (and >= 256); every block of the stripe then stores that item's ratings first, one single-
  * rating run per user, in user order.  Nothing is relaxed: the block is still walked sequentially in stored order,
- * and the free-block kernel (fp32, k = 64 or 128, no implicit term) walks a hot segment with the hot-item pipeline - the same
+ * and the free-block kernel (fp32, k = 64, 128 or 256, no implicit term) walks a hot segment with the hot-item pipeline - the same
  * chain of updates, restated so that the serial part of a link is a few scalar operations (Gram tile of the users'
  * rows on the matrix cores, csrc/epoch.hip phase_a_gram); every other kernel walks it through the item tickets.
  * The reference has no counterpart (its blocks are walked by one thread, RayBlockScheduler.py:127-143).

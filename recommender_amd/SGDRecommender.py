@@ -192,8 +192,8 @@ class Grid:
         _abi.check(_abi.lib().mfsgd_grid_status(self.handle, _abi.stream_ptr()))
 
     def set_hot_buffers(self, n):
-        """mfsgd_grid_set_hot_buffers: LDS row buffers (0..4) the hot-item pipeline may use in the free-block kernel;
-        0..8; 0 sends the hot segments through the item tickets like every other rating (same results up to rounding)."""
+        """mfsgd_grid_set_hot_buffers: LDS row buffers (0..8) the hot-item pipeline may use in the free-block kernel;
+        0 sends the hot segments through the item tickets like every other rating (same results up to rounding)."""
         _abi.check(_abi.lib().mfsgd_grid_set_hot_buffers(self.handle, int(n)))
 
     def set_pick_width(self, n):

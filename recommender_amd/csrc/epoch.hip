@@ -100,6 +100,38 @@ constexpr int MAX_PASSES_PER_LAUNCH = 200;   // visit counts live in one byte pe
 #define TICKET_NAP 3   // s_sleep units (64 clocks) a waiter sleeps per hand-off in front of it
 #endif
 
+// Hand-offs between the waves of a workgroup through LDS (item tickets, the pipeline's turn and frontier words): the payload
+// (an item row, a bias) is written with plain LDS stores, then the ticket word with a relaxed workgroup-scope atomic; the
+// next holder reads the ticket word and then the payload.
+//  * MFSGD_LDS_FENCE = 1 (make fenced): a workgroup-scope release / acquire fence restricted to the LDS address space
+//    between the two ("local": hipcc emits s_waitcnt lgkmcnt(0) only, the wave's HBM prefetches stay in flight).  The
+//    hand-off is then well defined in the memory model - at the price of a second LDS round trip on every link of an
+//    item's chain: netflix shape 23.9 -> 24.6 ms per epoch, through the tickets alone 37.0 -> 39.2, ML-25M 9.95 -> 10.4,
+//    ML-1M 1.18 -> 1.29 (profiles/r3_lds_fence_ab.txt).
+//  * MFSGD_LDS_FENCE = 0 (the shipped build): the INSTRUCTION order is pinned instead - an asm statement with a memory
+//    clobber is a barrier for the compiler at every level, so the payload's ds_write instructions are emitted before the
+//    ticket's and the ticket's ds_read before the payload's - and the LDS serves one wave's DS instructions in issue
+//    order (the hardware property every ds_read-after-ds_write of a single wave relies on).  `make` runs
+//    csrc/check_lds_order.py over the ISA and fails if a hand-off is not in that order.
+#ifndef MFSGD_LDS_FENCE
+#define MFSGD_LDS_FENCE 0
+#endif
+#if MFSGD_LDS_FENCE
+#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#else
+#define LDS_ACQUIRE()                                              \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+        asm volatile("; mf_lds_acquire" ::: "memory");             \
+    } while (0)
+#define LDS_RELEASE()                                              \
+    do {                                                           \
+        asm volatile("; mf_lds_release" ::: "memory");             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    } while (0)
+#endif
+
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // ------------------------------------------------------------------------------------------ grid build
@@ -584,7 +616,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             // drain vmcnt, i.e. stall the item's chain on this wave's prefetched HBM loads).
             for (int spins = 0;; ++spins) {
                 const int32_t seen = __hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order only
+                LDS_ACQUIRE();
 #pragma unroll
                 for (int c = 0; c < KC; ++c) {
                     const int f = lane + 64 * c;
@@ -648,7 +680,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                 if (FAST || f < k) qs[(size_t)il * k + f] = q[c];
             }
             *sink_ptr(&bis[il], ctl, lane) = bi;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            LDS_RELEASE();
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -832,7 +864,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
                 if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            LDS_ACQUIRE();
         }
         const float buj = __hip_atomic_load(&b_u[uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const float rest = hv[base + ej] - b - buj;
@@ -880,7 +912,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
             if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
             __builtin_amdgcn_s_sleep(2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler order; the LDS serves a wave in issue order
+        LDS_ACQUIRE();
         __builtin_amdgcn_s_setprio(2);
         PF_T(a3);
         PF_ADD(22, a2, a3);
@@ -940,7 +972,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 #pragma unroll
             for (int c = 0; c < KC; ++c) qrow[lane + 64 * c] = qn[c];
             *sink_ptr(bip, ctl, lane) = bi;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            LDS_RELEASE();
             __hip_atomic_store(sink_ptr(tok, ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -978,12 +1010,14 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
         {
             const int32_t last_user = m + 1 == nbatch ? 0x7fffffff : __builtin_amdgcn_readlane(uj, PA_B - 1);
             __hip_atomic_store(sink_ptr(fuser, ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            LDS_RELEASE();
             __hip_atomic_store(sink_ptr(front, ctl, lane), m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // the rest's gate: the minimum over all segments as this wave sees it now - never above the truth (the
             // words only grow), and raised with an atomic max so that a late, lower value cannot pull it back
             if constexpr (MULTI) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // no hand-off: whatever these reads return is a valid lower bound (the words only grow), and the wave's
+                // own store above is seen by its own reads (same wave, LDS in order); only the compiler must keep the order
+                asm volatile("" ::: "memory");
                 const int32_t fmin = hot_frontier(ctl, MAXSEG);
                 atomicMax(sink_ptr(&ctl[CTL_FMIN], ctl, lane), fmin);
             } else {   // batches are published in order: the one word only grows
@@ -1125,7 +1159,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
                         if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    LDS_ACQUIRE();
                     PF_T(i2);
                     PF_ADD(30, i1, i2);
                 }
@@ -1486,7 +1520,7 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     // ... unless the grid has hot segments and their pipeline can run: it needs the 128-register build, and hot segments
     // that go through the tickets cost more than the second workgroup gains
     const bool pipe = fast == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
-                      lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs).n_abuf > 0;
+                      lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs).n_abuf >= 2;   // one wave alone is no pipeline (ExplicitMF._pipeline_runs applies the same rule)
     const bool wps8 = can8 && !pipe && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
     auto kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 4> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 4> : k_epoch_free<T, KC, STAGE, 0, 4>;
     if constexpr (can8) {

@@ -20,6 +20,8 @@ void mfsgd_set_error(const char *fmt, ...)
 extern "C" const char *mfsgd_last_error(void) { return g_err; }
 extern "C" int mfsgd_version(void) { return 100; }
 
+int mfsgd_internal_scratch_init(void);
+
 extern "C" int mfsgd_device_check(void)
 {
     int n = 0;
@@ -37,6 +39,8 @@ extern "C" int mfsgd_device_check(void)
         mfsgd_set_error("device %d is %s; libmfsgd is built for gfx950 only", dev, prop.gcnArchName);
         return MFSGD_ERR_UNSUPPORTED;
     }
+    // set-up of the allocation-free entry point for this device (csrc/sgd_serial.hip)
+    if (const int rc = mfsgd_internal_scratch_init()) return rc;
     return n;
 }
 

@@ -19,7 +19,7 @@ constexpr int MAX_DEVICES = 64;
 static double *g_scratch_ptr[MAX_DEVICES];
 static std::mutex g_scratch_mu;
 
-static int scratch_ptr(double **out)
+static int scratch_ptr(double **out, int *dev_out)
 {
     int dev = 0;
     MF_HIP(hipGetDevice(&dev));
@@ -31,7 +31,17 @@ static int scratch_ptr(double **out)
         g_scratch_ptr[dev] = (double *)p;
     }
     *out = g_scratch_ptr[dev];
+    if (dev_out) *dev_out = dev;
     return MFSGD_OK;
+}
+
+// Resolves the current device's scratch address ahead of the first mfsgd_hip_rmse_noalloc_f32 call: the resolution
+// (hipGetSymbolAddress may load the code object) is neither capture-safe nor strictly allocation-free, so it belongs
+// to set-up.  mfsgd_device_check() - the library's init call, made with the device current - calls this.
+__attribute__((visibility("hidden"))) int mfsgd_internal_scratch_init(void)
+{
+    double *p = nullptr;
+    return scratch_ptr(&p, nullptr);
 }
 
 namespace {
@@ -296,9 +306,21 @@ int mfsgd_hip_rmse_noalloc_f32(const float *P, const float *Q, const float *b_u,
            (long long)n, (long long)MFSGD_RMSE_NOALLOC_MAX_N);
     MF_ARG(k <= MFSGD_RMSE_NOALLOC_MAX_K, "rmse_noalloc: k=%d exceeds the limit of %d factors", k,
            MFSGD_RMSE_NOALLOC_MAX_K);
+    MF_ARG(P && d_sse, "rmse_noalloc: null pointer");
     double *partials = nullptr;
-    const int rc = scratch_ptr(&partials);
+    int dev = 0;
+    const int rc = scratch_ptr(&partials, &dev);
     if (rc) return rc;
+    // the scratch is the CURRENT device's copy: outputs and inputs must live on that device (a pointer query, no
+    // stream work: legal under capture), else the kernels would be handed another GPU's array
+    for (const void *q : {(const void *)P, (const void *)d_sse}) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeDevice)
+            MF_ARG(at.device == dev, "rmse_noalloc: an argument lives on device %d but device %d is current (its scratch "
+                   "would be used): make the arguments' device current", at.device, dev);
+        else
+            (void)hipGetLastError();   // host-registered / managed / unknown: nothing to compare
+    }
     // every block overwrites its own partial and k_sum_partials reads only the blocks of THIS call:
     // nothing left behind by an earlier (larger) call is ever read, so nothing has to be cleared
     return rmse_impl<float>(P, Q, b_u, b_i, b, y, z, samples, n, stride, row_ptrs, col_inds, k, implicit, partials,

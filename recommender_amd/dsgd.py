@@ -200,8 +200,12 @@ class RankWorker:
                                                   _abi.ptr(log), _abi.stream_ptr()))
         self._calls += 1
 
-    def epoch(self, dist):
+    def epoch(self, dist, check=True):
+        """One epoch of the ring.  check: ask every shard grid whether a bounded wait ran out (mfsgd_grid_status) before
+        the epoch's results are used - a kernel that gave up leaves a shard half updated, and the ring would carry it on."""
         ring_epoch(self.plan, self.rank, self.Q, self.b_i, self.compute, dist)
+        if check:
+            self.status()
 
     def status(self):
         for g in self.grids:

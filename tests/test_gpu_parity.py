@@ -109,6 +109,27 @@ def test_rmse_vs_golden(ra, k):
     assert abs(ra.mse2(g["samples"], *f32, exact=True) - float(g["rmse_exact_init"])) < 1e-5
 
 
+@pytest.mark.parametrize("k", [4, 128])
+def test_mse_maps_to_the_a1_predictor(ra, orc, k):
+    """A4': numba_methods.mse (numba_methods.py:59-82) is broken in the reference (users[j+1], :76); the build maps it
+    to the exact RMSE of the A1 predictor.  exact=True: the golden value and the oracle; exact=False: the reference's
+    subsample SIZE for this function (n // 10 below 10 000 rows) drawn from the legacy global RNG - the same rows the
+    oracle then evaluates."""
+    g = load(f"kernels_k{k}.npz")
+    s = g["samples"]
+    args = (g["row_ptrs"], g["col_inds"], g["P"], g["Q"], g["b_u"], g["b_i"], float(g["b"]), g["y"])
+    assert abs(ra.mse(s, *args, exact=True) - float(g["rmse_exact_init"])) < 1e-10
+    assert abs(ra.mse(s, *args, exact=True) - orc.rmse(s, g["row_ptrs"], g["col_inds"], *args[2:], implicit=2)) < 1e-10
+    np.random.seed(5)
+    got = ra.mse(s, *args)
+    np.random.seed(5)
+    idx = np.random.choice(len(s), size=len(s) // 10, replace=False)
+    assert abs(got - orc.rmse(s[idx], g["row_ptrs"], g["col_inds"], *args[2:], implicit=2)) < 1e-10
+    import torch        # device tensors go straight through
+    dev = tuple(torch.from_numpy(np.ascontiguousarray(a)).cuda() if isinstance(a, np.ndarray) else a for a in args)
+    assert abs(ra.mse(torch.from_numpy(s).cuda(), *dev, exact=True) - float(g["rmse_exact_init"])) < 1e-10
+
+
 # ------------------------------------------------------------------ D1-D4 through ExplicitMF
 @pytest.mark.parametrize("tag", ["a", "b", "shuf", "ragged"])
 def test_prep_bit_exact_through_explicitmf(ra, tag):
@@ -379,7 +400,7 @@ def test_overlapped_passes_replay_on_oracle(ra, orc):
     assert seen_overlap
 
 
-@pytest.mark.parametrize("hot_bufs", [0, 1, 8])
+@pytest.mark.parametrize("hot_bufs", [0, 2, 8])
 def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_bufs):
     """Blocks whose stripe has a hot item store that item's ratings as a segment in front.  hot_bufs = 0 walks the
     segment through the item's tickets like any other rating; hot_bufs > 0 sends it through the hot-item pipeline
