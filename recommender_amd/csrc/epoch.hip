@@ -479,6 +479,72 @@ __device__ __forceinline__ void untracked_store(double *p, double v)
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
+// Lane -> factor map of the walk (load_run / walk_run): lane l holds the KC CONSECUTIVE factors KC*l .. KC*l + KC-1 of a
+// row, so a row moves with ONE access per lane - global_load_dwordx2 / ds_read_b64 at k = 128, dwordx4 / b128 at k = 256
+// (fp32; twice that in fp64) - instead of KC dword accesses at stride 64.  The dot product sums over all lanes and
+// registers, so it does not care; the hot-item pipeline keeps its own (lane + 64 c) map for its LDS row buffers.
+template <typename T, int KC> struct RowVec { typedef T type __attribute__((ext_vector_type(KC))); };
+template <typename T, int KC>
+__device__ __forceinline__ void row_get(const T *row, int lane, T (&x)[KC])
+{
+    if constexpr (KC == 2 || KC == 4) {
+        const typename RowVec<T, KC>::type v = *(const typename RowVec<T, KC>::type *)(row + KC * lane);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) x[c] = v[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) x[c] = row[KC * lane + c];
+    }
+}
+template <typename T, int KC>
+__device__ __forceinline__ void row_put(T *row, int lane, const T (&x)[KC])
+{
+    if constexpr (KC == 2 || KC == 4) {
+        typename RowVec<T, KC>::type v;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) v[c] = x[c];
+        *(typename RowVec<T, KC>::type *)(row + KC * lane) = v;
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) row[KC * lane + c] = x[c];
+    }
+}
+// the same store outside the compiler's vmcnt bookkeeping (see walk_run's tail)
+template <int KC>
+__device__ __forceinline__ void row_put_untracked(float *row, int lane, const float (&x)[KC])
+{
+    float *p = row + KC * lane;
+    if constexpr (KC == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 v = {x[0], x[1]};
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (KC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = {x[0], x[1], x[2], x[3]};
+        // a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers (two wait
+        // states on gfx90a-class targets); hipcc's hazard recognizer cannot see into the asm statement
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) asm volatile("global_store_dword %0, %1, off" ::"v"(p + c), "v"(x[c]) : "memory");
+    }
+}
+template <int KC>
+__device__ __forceinline__ void row_put_untracked(double *row, int lane, const double (&x)[KC])
+{
+    double *p = row + KC * lane;
+    if constexpr (KC == 2) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 v = {x[0], x[1]};
+        // a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers (two wait
+        // states on gfx90a-class targets); hipcc's hazard recognizer cannot see into the asm statement
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p + c), "v"(x[c]) : "memory");
+    }
+}
+
 // Stage 1 of a run: which run, whose, and where its ratings are (wave-uniform words).
 struct RunIdx {
     int32_t j, u, t0, t1;
@@ -528,16 +594,23 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     h.t0 = __builtin_amdgcn_readfirstlane(x.t0);
     h.t1 = __builtin_amdgcn_readfirstlane(x.t1);
     const T *prow = P + (int64_t)h.u * k;
+    if constexpr (FAST != 0) {
+        row_get<T, KC>(prow, lane, h.p);
+        if constexpr (FAST == 2) {
+            row_get<T, KC>(z + (int64_t)h.u * k, lane, h.zz);
+        } else {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const int f = lane + 64 * c;
-        h.p[c] = 0; h.zz[c] = 0;
-        if (FAST) {
-            h.p[c] = prow[f];
-            if (FAST == 2) h.zz[c] = z[(int64_t)h.u * k + f];
-        } else if (f < k) {
-            h.p[c] = prow[f];
-            if (z) h.zz[c] = z[(int64_t)h.u * k + f];
+            for (int c = 0; c < KC; ++c) h.zz[c] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int f = KC * lane + c;
+            h.p[c] = 0; h.zz[c] = 0;
+            if (f < k) {
+                h.p[c] = prow[f];
+                if (z) h.zz[c] = z[(int64_t)h.u * k + f];
+            }
         }
     }
     // biases are rewritten by other workgroups earlier in this launch: atomic loads never become scalar loads
@@ -617,10 +690,14 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             for (int spins = 0;; ++spins) {
                 const int32_t seen = __hip_atomic_load(&tick_done[il], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 LDS_ACQUIRE();
+                if constexpr (FAST != 0) {
+                    row_get<T, KC>(qs + (size_t)il * k, lane, q);
+                } else {
 #pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const int f = lane + 64 * c;
-                    q[c] = (FAST || f < k) ? qs[(size_t)il * k + f] : (T)0;
+                    for (int c = 0; c < KC; ++c) {
+                        const int f = KC * lane + c;
+                        q[c] = f < k ? qs[(size_t)il * k + f] : (T)0;
+                    }
                 }
                 bi = bis[il];
                 int32_t ahead = tk - __builtin_amdgcn_readfirstlane(seen);
@@ -655,7 +732,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // Q is in global memory: full fence
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                const int f = lane + 64 * c;
+                const int f = KC * lane + c;
                 q[c] = f < k ? qrow[f] : (T)0;
             }
             bi = __hip_atomic_load(&b_i[ig], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -674,17 +751,21 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         T pn[KC];
         const T e = sgd_step<T, KC, FAST != 1>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
+            if constexpr (FAST != 0) {
+                row_put<T, KC>(qs + (size_t)il * k, lane, q);
+            } else {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const int f = lane + 64 * c;
-                if (FAST || f < k) qs[(size_t)il * k + f] = q[c];
+                for (int c = 0; c < KC; ++c) {
+                    const int f = KC * lane + c;
+                    if (f < k) qs[(size_t)il * k + f] = q[c];
+                }
             }
             *sink_ptr(&bis[il], ctl, lane) = bi;
             LDS_RELEASE();
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                const int f = lane + 64 * c;
+                const int f = KC * lane + c;
                 if (f < k) qrow[f] = q[c];
             }
             __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
@@ -711,13 +792,12 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
         // prefetched load into vmcnt(0) - the whole pipeline would drain once per run.  Untracked stores only
         // make its counted waits a little more conservative (the real queue is longer than it thinks),
         // never less.  process_block drains vmcnt(0) by hand before the block's closing barrier.
-#pragma unroll
-        for (int c = 0; c < KC; ++c) untracked_store(prow + lane + 64 * c, p[c]);
+        row_put_untracked<KC>(prow, lane, p);
         untracked_store(&b_u[u], bu);   // all lanes, same word
     } else {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            const int f = lane + 64 * c;
+            const int f = KC * lane + c;
             if (f < k) prow[f] = p[c];
         }
         __hip_atomic_store(&b_u[u], bu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
