@@ -97,7 +97,7 @@ def run_leg(args, torch, ra, data, k, hot_buffers, renumber=None):
     train, test, U, I = data
     m = ra.ExplicitMF(n_threads=15, n_factors=k, alpha=ALPHA, beta1=BETA1, beta2=BETA2, implicit=args.implicit,
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
-                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers,
+                      n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers, hot_mode=args.hot_mode,
                       **({} if args.hot_items < 0 else {"hot_items": args.hot_items}),
                       **({} if args.hot_cost < 0 else {"hot_cost": args.hot_cost}),
                       **({} if args.hot_min < 0 else {"hot_min": args.hot_min}), verbose=False)
@@ -158,6 +158,8 @@ def main():
                     help="hot items (hot segments per block) a stripe may have where the pipeline runs (default: the library's)")
     ap.add_argument("--hot-min", type=int, default=-1,
                     help="ratings per block an item needs to become a hot item (default: the model's, 64)")
+    ap.add_argument("--hot-mode", type=int, default=2,
+                    help="hot segments: 2 = hot-item walker (default), 1 = matrix-core pipeline, 0 = item tickets")
     ap.add_argument("--hot-buffers", type=int, default=8,
                     help="LDS row buffers of the hot-item pipeline (mfsgd_grid_set_hot_buffers); 0 = every rating "
                          "through the item tickets.  Either way a block is walked sequentially in stored order")

@@ -200,6 +200,18 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
  * take behind the stripe; 0 sends hot segments through the tickets too (same results up to rounding - the tests
  * replay both on the oracle's plain sequential kernel).  Takes effect from the next epoch call. */
 int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n);
+/* How the free-block kernel walks hot segments (takes effect from the next epoch call):
+ *   2 (default)  the hot-item WALKER for stripes with one hot item: one wave keeps the item's row in registers for the
+ *                whole segment and streams the users' rows through a ring of register slots, requested straight from
+ *                HBM 8-32 links ahead (csrc/epoch.hip phase_a_serial) - no ticket, no LDS hand-off, a link is ~130
+ *                cycles of dependent issue.  Every straight-line build: fp32 / fp64, k = 64, 128, 192, 256, with or
+ *                without the frozen implicit term, no LDS beyond the stripe.  Stripes with several hot items take the
+ *                matrix-core pipeline (mode 1) where it can run, else the tickets;
+ *   1            the matrix-core pipeline only (phase_a_gram; fp32, k = 64 / 128 / 256, no implicit term, row buffers
+ *                in LDS - mfsgd_grid_set_hot_buffers);
+ *   0            every rating through the item tickets (as mfsgd_grid_set_hot_buffers(g, 0)).
+ * All three are the same sequential pass over the block's stored order. */
+int mfsgd_grid_set_hot_mode(mfsgd_grid *g, int32_t mode);
 /* schedule 2 of mfsgd_hip_epoch_*: of the first `n` free user stripes a workgroup finds (1..64; default 3) it takes the one
  * its item stripe has visited least often in this launch.  1 = any free stripe (passes blur most), 64 = practically the
  * least visited free stripe (passes nearly in step).  The counterpart of the reference's "minimal update count among the

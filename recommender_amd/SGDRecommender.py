@@ -151,6 +151,7 @@ def lds_bytes(ibp, Gr, k, esz, hot_bufs=0):
     pipeline (float32 only, 32 rows of k + 4 floats each) on top."""
     up = lambda x: (x + 15) & ~15
     o = up((16 + 128 + 5 * _abi.MAX_HOT + 4) * 4)
+    o = up(o + 4 * 64 * esz)            # the hot-item walker's error words (HOT_EBUFS chunks of 64)
     o = up(o + ibp * 4)
     o = up(o + Gr)
     o = up(o + Gr * 16)
@@ -195,6 +196,11 @@ class Grid:
         """mfsgd_grid_set_hot_buffers: LDS row buffers (0..8) the hot-item pipeline may use in the free-block kernel;
         0 sends the hot segments through the item tickets like every other rating (same results up to rounding)."""
         _abi.check(_abi.lib().mfsgd_grid_set_hot_buffers(self.handle, int(n)))
+
+    def set_hot_mode(self, mode):
+        """mfsgd_grid_set_hot_mode: 2 = hot-item walker (one wave, item row in registers; default), 1 = matrix-core
+        pipeline, 0 = item tickets."""
+        _abi.check(_abi.lib().mfsgd_grid_set_hot_mode(self.handle, int(mode)))
 
     def set_pick_width(self, n):
         """mfsgd_grid_set_pick_width: schedule 2 takes the least visited of the first `n` free user stripes."""
@@ -253,6 +259,7 @@ class ExplicitMF(Recommender):
                  exact_errors=True,      # geterrors over all rows (the reference subsamples, mse2)
                  hot_buffers=None,       # LDS row buffers of the hot-item pipeline (None = 8, as many as fit; 0 = ticket path only)
                  hot_items=1,            # hot items (hot segments per block) a stripe may have where the pipeline runs (<= 8)
+                 hot_mode=2,             # hot segments: 2 = register-resident walker (one hot item per stripe), 1 = matrix-core pipeline, 0 = tickets
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
                  hot_min=64,             # ratings per block (on average) an item needs to become a hot item (two pipeline batches)
                  pad_factors=True,       # throughput mode: device copies of P / Q / y get zero columns up to a multiple of 64
@@ -275,6 +282,7 @@ class ExplicitMF(Recommender):
         self.exact_errors = exact_errors
         self.hot_buffers = 8 if hot_buffers is None else int(hot_buffers)
         self.hot_items = int(hot_items)
+        self.hot_mode = int(hot_mode)
         self.hot_cost = hot_cost
         self.hot_min = int(hot_min)
         self.pad_factors = bool(pad_factors)
@@ -378,13 +386,29 @@ class ExplicitMF(Recommender):
             return k
         return kd
 
+    def _walker_runs(self, Gr, Gc):
+        """Will the free-block launch walk hot segments with the hot-item walker (csrc/epoch.hip phase_a_serial)?  Any
+        straight-line build (device rows a multiple of 64 factors, float32 or float64, with or without the frozen
+        term) whose stripes sit in LDS, one hot item per stripe."""
+        if self.deterministic or self.hot_mode != 2 or self.hot_items != 1 or self.hot_buffers <= 0:
+            return False
+        kd = self._device_k()
+        esz = 8 if self.dtype == "float64" else 4
+        # a ring slot is one 4 / 8 / 16-byte load per lane: k = 64, 128, 256 in float32, 64 and 128 in float64
+        if kd not in (64, 128, 256) or (kd // 64) * esz > 16 or (self.implicit or "frozen") == "full":
+            return False
+        return lds_bytes(-(-self.n_items // Gc), Gr, kd, esz) <= 160 * 1024
+
+    def _hot_path_runs(self, Gr, Gc):
+        return self._walker_runs(Gr, Gc) or self._pipeline_runs(Gr, Gc)
+
     def _pipeline_kernel(self):
         """The hot-item pipeline is worth its hot segments for fp32, k = 64 or 128, no implicit term.  The kernel also
         exists for k = 256 (csrc/epoch.hip, FASTA; parity-tested), but a batch's row buffer is 33 KB there, two fit
         next to a stripe, and two pipeline waves are slower than the tickets (netflix shape, k = 256: 74 ms per epoch
         against 56 ms), so the chooser does not ask for hot segments at k = 256."""
         return (self.dtype != "float64" and self._device_k() in (64, 128) and (self.implicit or "frozen") == "none"
-                and self.hot_buffers > 0)
+                and self.hot_buffers > 0 and self.hot_mode >= 1)
 
     def _pipeline_runs(self, Gr, Gc):
         """Will the free-block launch walk hot segments with the pipeline on a Gr x Gc grid?  It does when the kernel
@@ -448,13 +472,15 @@ class ExplicitMF(Recommender):
             # two pipeline batches (64 ratings) per block on average: a batch costs ~9 us of row gather and Gram tile
             # before its first link (ML-1M shape: 93 x 75 blocks 1.26 ms per epoch without hot segments, 1.70 ms with
             # items of 32+ ratings per block; 64 x 56 blocks 1.18 against 1.41)
-            runs = self._pipeline_runs(-(-self.n_users // ubp), -(-self.n_items // ibp))
+            runs = self._hot_path_runs(-(-self.n_users // ubp), -(-self.n_items // ibp))
             hot = (self.hot_items, self.hot_min) if runs and self.hot_items > 0 else 0
             self._grid = Grid(self._d_samples, self.n_users, self.n_items, ubp, ibp, order=1, hot_segments=hot)
         if self.hot_buffers != 8:
             self._grid.set_hot_buffers(self.hot_buffers)
         if self.pick_width is not None:
             self._grid.set_pick_width(self.pick_width)
+        if self.hot_mode != 2:
+            self._grid.set_hot_mode(self.hot_mode)
         return self._grid
 
     def _to_dev(self):
@@ -628,7 +654,7 @@ class ExplicitMF(Recommender):
         du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
         di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
         Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
-        cost = item_costs(di, Gr, Gc, self._pipeline_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min)
+        cost = item_costs(di, Gr, Gc, self._hot_path_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min)
         self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):

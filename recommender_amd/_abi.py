@@ -72,6 +72,7 @@ SIGNATURES = {
     "mfsgd_lds_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "mfsgd_grid_set_hot_buffers": (C.c_int, [c_vp, c_i32]),
     "mfsgd_grid_set_pick_width": (C.c_int, [c_vp, c_i32]),
+    "mfsgd_grid_set_hot_mode": (C.c_int, [c_vp, c_i32]),
     "mfsgd_dsgd_plan": (C.c_int, [c_i64, c_i64, c_i32, c_i32, c_i32, C.POINTER(c_i64), C.POINTER(c_i64),
                                   C.POINTER(c_i32), C.POINTER(c_i32)]),
     "mfsgd_dsgd_schedule": (C.c_int, [c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)]),

@@ -63,6 +63,7 @@ struct mfsgd_grid {
     int32_t max_block_runs = 0;
     int32_t hot_bufs = PA_MAX_BUFS_DEFAULT;   // LDS row buffers the hot-item pipeline may take (0: ticket path only)
     int32_t pick_width = PICK_WIDTH_DEFAULT;  // schedule 2: free user stripes among which the least visited one is taken
+    int32_t hot_mode = 2;                     // how the free-block kernel walks hot segments: 0 tickets, 1 matrix-core pipeline, 2 walker
     int32_t *row_lock = nullptr;   // [Gr]
     int32_t *counters = nullptr;   // [0] next column, [1] next log slot; padded to 16 words
     long long *col_clock = nullptr;  // [Gc][2] start/end of each column tenure (100 MHz realtime), last epoch
@@ -436,9 +437,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 }
 
 template <typename T> struct LdsPlan {  // byte offsets inside the dynamic LDS region (all multiples of 16)
-    uint32_t ctl, tick, rowdone, rowrun, qs, bis, rt_u, rt_t, abuf, abuf_bytes, total;
+    uint32_t ctl, ebuf, tick, rowdone, rowrun, qs, bis, rt_u, rt_t, abuf, abuf_bytes, total;
     int32_t n_abuf;   // row buffers of the hot-item pipeline (phase_a_gram); 0: hot segments go through the tickets
+    int32_t hot_walker;   // 1: stripes with one hot item get the register-resident walker (phase_a_serial)
 };
+constexpr int HOT_EBUFS = 4;   // chunks of 64 errors the walker's chain wave may be ahead of its apply wave
 constexpr int RT_CAP = 1024;  // runs per block the LDS run table takes (the default 288 x 256 netflix grid has ~720 per block)
 constexpr int PA_B = 32;      // ratings per batch of the hot-item pipeline (one 32 x 32 MFMA tile of Gram entries)
 constexpr int PA_MAX_BUFS = PA_MAX_BUFS_DEFAULT;
@@ -453,6 +456,7 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
     LdsPlan<T> p{};
     size_t o = 0;
     p.ctl = o; o = up(o + CTL_WORDS * 4);
+    p.ebuf = o; o = up(o + (size_t)HOT_EBUFS * 64 * sizeof(T));   // the hot-item walker's error words, chain wave -> apply wave
     p.tick = o; o = up(o + (size_t)ibp * 4);
     p.rowdone = o; o = up(o + (dynamic ? (size_t)Gr : 0));
     p.rowrun = o; o = up(o + (dynamic ? (size_t)Gr * 16 : 0));
@@ -1114,6 +1118,269 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
     }   // segments
 }
 
+// ------------------------------------------------------------------------------------ the hot-item walker (round 3)
+// The same hot segment, walked by ONE wave that keeps the item's row in its REGISTERS for the whole segment: no
+// ticket, no LDS hand-off, no Gram tile - a link is dot product, wave reduction, the two row updates (~130 cycles of
+// dependent issue), and nothing of it waits for memory because the segment's users are known in advance (single-rating
+// runs in user order): their rows stream through a ring of HOT_RING register slots, requested HOT_RING links ahead
+// straight from HBM, the user ids / ratings / biases 64 links at a time one chunk ahead.  The arithmetic is walk_run's,
+// operation by operation (same lane -> factor map, same reduction tree), so the result is the sequential pass to the
+// bit the ticket path gives.  Works for every straight-line build - fp32 and fp64, k = 64 .. 256, with the frozen
+// implicit term (its z row rides in a second ring) - and needs no LDS beyond the stripe, so it also runs where the
+// stripes fill the LDS (ML-25M shape) and the matrix-core pipeline has no room for its row buffers.
+// One hot item per stripe (the default); stripes with several hot items go through phase_a_gram or the tickets.
+// The rest of the block runs meanwhile on the other waves, the runs of the segment's users behind the frontier word
+// (CTL_FMIN), which this wave raises ONCE, when the segment is through and its row stores have drained (raising it
+// chunk by chunk would mean draining the ring of requested rows every 64 links; the segment takes a fraction of the
+// time the other waves need for the runs that wait for nothing).
+#ifndef MFSGD_HOT_RING_REGS
+#define MFSGD_HOT_RING_REGS 32
+#endif
+template <typename T, int KC, bool HASZ> struct HotRing {   // register slots: MFSGD_HOT_RING_REGS VGPRs of rows at most, 32 slots at most
+    static constexpr int regs = KC * (HASZ ? 2 : 1) * (int)(sizeof(T) / 4);
+    static constexpr int value = MFSGD_HOT_RING_REGS / regs >= 32 ? 32 : MFSGD_HOT_RING_REGS / regs >= 16 ? 16 : MFSGD_HOT_RING_REGS / regs >= 8 ? 8 : 4;
+};
+// The walker issues its row loads and waits for them BY HAND (hipcc's wait insertion, fed with a loop that carries 32
+// loads in flight across its back edge and stores it does not see, put `s_waitcnt vmcnt(4)` in front of every link):
+// a load writes its destination register whenever the memory system answers, the only interlock is the counted wait.
+//   vm_load: the destination is a read-write operand, so it stays in ONE register from the request to the wait;
+//   vm_wait<N>: "at most N vector memory operations still outstanding"; loads complete in the order they were issued,
+//     so with N = the number of LOADS issued after the wanted one it has arrived (stores, which may complete out of
+//     order relative to loads, only make the wait earlier than necessary, never later).
+template <typename V> struct VmBytes { static constexpr int value = (int)sizeof(V); };
+template <typename V>
+__device__ __forceinline__ void vm_load(V &dst, const void *addr)
+{
+    if constexpr (sizeof(V) == 4) asm volatile("global_load_dword %0, %1, off" : "+v"(dst) : "v"(addr) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(dst) : "v"(addr) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(addr) : "memory");
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "vm_load: 4, 8 or 16 bytes per lane");
+}
+// the same with the address as a 64-bit scalar base plus a 32-bit per-lane byte offset (one v_add instead of a 64-bit
+// address computation per request)
+template <typename V>
+__device__ __forceinline__ void vm_load_so(V &dst, const void *sbase, uint32_t voff)
+{
+    if constexpr (sizeof(V) == 4) asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void vm_store_so(const V &src, void *sbase, uint32_t voff)
+{
+    if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");   // > 64 bits: hazard nop
+}
+__device__ __forceinline__ float fma_t(float x, float y, float w) { return __builtin_fmaf(x, y, w); }
+__device__ __forceinline__ double fma_t(double x, double y, double w) { return __builtin_fma(x, y, w); }
+template <int N, typename V>
+__device__ __forceinline__ void vm_wait(V &slot)
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "n"(N) : "memory");
+}
+template <typename T, int KC> struct RowReg { typedef typename RowVec<T, KC>::type type; };
+template <typename T> struct RowReg<T, 1> { typedef T type; };
+template <typename T, int KC> __device__ __forceinline__ T row_elem(const typename RowReg<T, KC>::type &v, int c)
+{
+    if constexpr (KC == 1) return v; else return v[c];
+}
+
+// wave64 sum for the walker's chain: wave_sum's tree (same result bit for bit) with the two row broadcasts as single
+// v_add_f32_dpp instructions (hipcc expands the masked broadcast into v_mov 0 / v_mov_dpp / v_add: 4 instructions more
+// on a chain where every instruction is ~5 cycles)
+__device__ __forceinline__ float chain_sum(float v)
+{
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    // rows 1 and 3 += the row before, then rows 2 and 3 += row 1 / row 1 + ... : lane 63 ends with (r0 + r1) + (r2 + r3)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double chain_sum(double v) { return wave_sum(v); }
+
+// ROLE 0 = the CHAIN wave: dot product, reduction, error, the item row's update - the serial part of every link and
+// nothing else; it issues loads only, so its counted waits are exact and all HOT_RING rows stay in flight.  Per chunk of
+// 64 links it leaves the 64 errors in LDS (ebuf) and bumps CTL_TOKEN.
+// ROLE 1 = the APPLY wave, a chunk behind: with the errors known it runs the item row forward once more (the same
+// operations on the same inputs: the same rows q_j) and forms, stores and publishes the users' new rows and biases.
+// One update with a = 1 - alpha beta2 (numba_methods.py:21-22):  p' = a p + (alpha e) q,   q' = a q + (alpha e)(p' + z).
+template <typename T, int KC, bool HASZ, int ROLE>
+__device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int32_t t_lo, int32_t nh, int32_t hot_item,
+                                         int32_t c_base, T *__restrict__ P, T *__restrict__ b_u, const T *__restrict__ z,
+                                         T b, T alpha, T beta1, T beta2, int k, T *qs, T *bis, int *ctl, T *ebuf,
+                                         int32_t *err)
+{
+    constexpr int D = HotRing<T, KC, HASZ>::value;   // divides 64
+    constexpr int L = HASZ ? 2 : 1;                  // loads per link
+    typedef typename RowReg<T, KC>::type Row;
+    const int lane = threadIdx.x & 63;
+    T *qrow = qs + (size_t)(hot_item - c_base) * k;
+    T *bip = bis + (hot_item - c_base);
+    const int32_t *hu = g.run_user + run_lo;     // the segment's users (single-rating runs) and ratings, straight from the grid
+    const float *hv = g.val + t_lo;
+    const T a = (T)1 - alpha * beta2, a1 = (T)1 - alpha * beta1;
+    const uint32_t lane_off = (uint32_t)(KC * lane * sizeof(T)), row_bytes = (uint32_t)(k * sizeof(T));   // n_users * k * sizeof(T) < 2^32 (host check)
+    T q[KC];
+    row_get<T, KC>(qrow, lane, q);               // q_0: both waves start from the stripe's row
+    T bi = *bip;
+    if constexpr (ROLE == 1) {                   // the chain wave writes the row back only after this (short segments)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[KC - 1]));
+        __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN + 1], ctl, lane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // Metadata, 64 links per chunk, one link per lane (entries past the segment's end repeat its last link: valid
+    // addresses, never applied): user ids and ratings are requested TWO chunks ahead, the users' biases - a gather that
+    // needs the ids - one chunk ahead, so nothing in the loop waits for a load it has just issued.
+    auto ids = [&](int32_t base, int32_t &uj, float &vj) {
+        int32_t j = base + lane;
+        j = j < nh ? j : nh - 1;
+        vm_load(uj, hu + j);
+        vm_load(vj, hv + j);
+    };
+    int32_t ujA = 0, ujB = 0, ujC = 0;
+    float vA = 0, vB = 0, vC = 0;
+    T buA = 0, buB = 0;
+    ids(0, ujA, vA);
+    ids(64, ujB, vB);
+    ids(128, ujC, vC);
+    vm_wait<0>(ujA);
+    asm volatile("" : "+v"(ujB), "+v"(vA), "+v"(vB), "+v"(ujC), "+v"(vC));   // all six have arrived
+    vm_load(buA, b_u + ujA);
+    vm_load(buB, b_u + ujB);
+    Row rp[D], rz[HASZ ? D : 1];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        rp[s] = Row{};
+        if constexpr (HASZ) rz[s] = Row{};
+        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane(ujA, s) * row_bytes + lane_off;
+        vm_load_so(rp[s], P, ro);
+        if constexpr (HASZ) vm_load_so(rz[s], z, ro);
+    }
+    // per-lane byte offset of every link's row: one readlane + one v_add per request in the loop
+    uint32_t offA = (uint32_t)ujA * row_bytes, offB = (uint32_t)ujB * row_bytes;
+    vm_wait<D * L>(buA);                       // the biases are older than the ring's rows
+    asm volatile("" : "+v"(buB));
+    if constexpr (ROLE == 0) __builtin_amdgcn_s_setprio(3);   // the item's chain: everything else in the block waits behind it
+    int32_t chunk = 0;
+    for (int32_t base = 0; base < nh; base += 64, ++chunk) {
+        const int32_t nb = nh - base;                            // links left, this chunk included
+        T restA = 0, evec = 0;
+        T *eb = ebuf + (chunk % HOT_EBUFS) * 64;
+        if constexpr (ROLE == 0) {
+            restA = (T)vA - b - buA;
+            // the error buffer of chunk c is free once the apply wave has read chunk c - HOT_EBUFS
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_FRONT], __ATOMIC_RELAXED,
+                                                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) < chunk - (HOT_EBUFS - 1); ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN], __ATOMIC_RELAXED,
+                                                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) <= chunk; ++spins) {
+                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            LDS_ACQUIRE();
+            evec = eb[lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(evec));
+        }
+        // the chunk is straight-line code: every lane index below is a constant, every load unconditional
+#pragma unroll
+        for (int li = 0; li < 64; ++li) {
+            constexpr int DD = D;
+            const int s = li % DD;
+            // ROLE 1 also has a store per link in the queue: counting loads only makes its wait early, never late
+            if constexpr (HASZ) { vm_wait<(DD - 1) * L>(rz[s]); asm volatile("" : "+v"(rp[s])); }
+            else vm_wait<(DD - 1) * L>(rp[s]);
+            if (li < nb) {                                       // wave-uniform
+                T ap[KC], aq[KC], pn[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) { ap[c] = a * row_elem<T, KC>(rp[s], c); aq[c] = a * q[c]; }
+                T e;
+                if constexpr (ROLE == 0) {
+                    T part = q[0] * (HASZ ? row_elem<T, KC>(rp[s], 0) + row_elem<T, KC>(rz[s], 0) : row_elem<T, KC>(rp[s], 0));
+#pragma unroll
+                    for (int c = 1; c < KC; ++c)
+                        part = fma_t(q[c], HASZ ? row_elem<T, KC>(rp[s], c) + row_elem<T, KC>(rz[s], c)
+                                                : row_elem<T, KC>(rp[s], c), part);
+                    T ri;
+                    if constexpr (sizeof(T) == 4) ri = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(restA), li));
+                    else ri = __shfl(restA, li, 64);
+                    e = (ri - bi) - chain_sum(part);
+                    bi = fma_t(alpha, e, a1 * bi);               // b_i' = b_i + alpha (e - beta1 b_i)
+                    eb[li] = e;                                  // every lane, same word: one ds_write with an immediate offset
+                } else {
+                    if constexpr (sizeof(T) == 4) e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(evec), li));
+                    else e = __shfl(evec, li, 64);
+                }
+                const T ae = alpha * e;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    pn[c] = fma_t(ae, q[c], ap[c]);
+                    q[c] = fma_t(ae, HASZ ? pn[c] + row_elem<T, KC>(rz[s], c) : pn[c], aq[c]);
+                }
+                if constexpr (ROLE == 1) {
+                    Row out;
+                    if constexpr (KC == 1) out = pn[0];
+                    else {
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) out[c] = pn[c];
+                    }
+                    vm_store_so(out, P, (uint32_t)__builtin_amdgcn_readlane(offA, li) + lane_off);
+                }
+            }
+            // the slot is free: request the row of the link HOT_RING further on
+            const uint32_t ro = (uint32_t)(li + DD < 64 ? __builtin_amdgcn_readlane(offA, (li + DD) & 63)
+                                                        : __builtin_amdgcn_readlane(offB, (li + DD) & 63)) + lane_off;
+            vm_load_so(rp[s], P, ro);
+            if constexpr (HASZ) vm_load_so(rz[s], z, ro);
+        }
+        if constexpr (ROLE == 0) {
+            LDS_RELEASE();
+            __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            // the users' biases (numba_methods.py:19); the error buffer is free again
+            if (lane < nb) untracked_store(&b_u[ujA], buA + alpha * (evec - beta1 * buA));
+            __hip_atomic_store(sink_ptr(&ctl[CTL_FRONT], ctl, lane), chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // The metadata moves up one chunk.  Everything copied here was requested at least a chunk ago - before ring rows
+        // that have been waited for since - so it has arrived.
+        ujA = ujB; vA = vB; buA = buB;
+        ujB = ujC; vB = vC;
+        offA = offB; offB = (uint32_t)ujB * row_bytes;
+        asm volatile("" : "+v"(ujA), "+v"(vA), "+v"(buA), "+v"(ujB), "+v"(vB), "+v"(offA), "+v"(offB));   // the copies happen HERE, before the reloads
+        vm_load(buB, b_u + ujB);
+        ids(base + 192, ujC, vC);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests land before their registers are reused
+    if constexpr (ROLE == 0) {
+        __builtin_amdgcn_s_setprio(0);
+        // the item's row goes back to the stripe - once the apply wave has taken its copy of q_0
+        for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN + 1], __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; ++spins) {
+            if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        row_put<T, KC>(qrow, lane, q);
+        *sink_ptr(bip, ctl, lane) = bi;
+    } else {
+        // the segment's users are done (their stores have drained): publish
+        __hip_atomic_store(sink_ptr(&ctl[CTL_FUSER], ctl, lane), 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        LDS_RELEASE();
+        __hip_atomic_store(sink_ptr(&ctl[CTL_FMIN], ctl, lane), 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // All threads of the workgroup call this; ends with a barrier after which every store of the block has been
 // issued AND completed (vmcnt drained per wave).
 // Runs [run_lo, run_lo + n_hot_blk) are the block's hot segments, one after the other (segment s: one single-rating run
@@ -1122,13 +1389,14 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 // finished - stores drained, barrier - before the next starts.  FASTA: the hot segments go through the hot-item
 // pipeline (phase_a_gram) when the launch gave it LDS row buffers, concurrently with the rest behind its user
 // frontier; otherwise they are walked like any other run, through the items' tickets.
-template <typename T, int KC, bool STAGE, int FAST, bool FASTA>
+template <typename T, int KC, bool STAGE, int FAST, bool FASTA, bool SERIAL = false>
 __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int32_t c, T *P, T *Q, T *b_u, T *b_i, T b,
                                               const T *z, T alpha, T beta1, T beta2, int variant, int k, int *ctl,
                                               int *tick_done, T *qs, T *bis, int32_t *err, int *rt_u, int *rt_t,
                                               int32_t run_lo, int32_t run_hi, int32_t n_hot_blk, int32_t n_free_runs,
-                                              char *abuf, uint32_t abuf_bytes, int n_abuf PF_PARAM)
+                                              char *abuf, uint32_t abuf_bytes, int n_abuf, int hot_walker, T *ebuf PF_PARAM)
 {
+    constexpr bool GATED = FASTA || SERIAL;   // builds in which hot segments may run beside the rest, behind the frontier
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     PF_T(b0);
     const int32_t c_base = c * g.ibp;
@@ -1154,8 +1422,10 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     }
     bool gated = false;   // the pipeline walks the hot segments WHILE the other waves walk the rest behind its frontier
     int first_pass = 0;
-    if constexpr (FASTA) {
-        if (n_abuf > 0 && n_hot_blk > 0) {
+    // the register-resident walker takes stripes with ONE hot item; the matrix-core pipeline needs its row buffers
+    const bool serial = SERIAL && hot_walker && !multi && n_hot_blk > 0 && variant == 0 && nw >= 2;
+    if constexpr (GATED) {
+        if ((serial || (FASTA && n_abuf > 0)) && n_hot_blk > 0) {
             gated = true;
             first_pass = MAXSEG;
             // every thread, same values; made visible by the barrier behind the first run table below
@@ -1194,8 +1464,20 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
     __syncthreads();
     PF_T(bs);
     PF_ADD(19, b0, bs);
+    if constexpr (SERIAL) {
+        if (gated && serial && lo == seg_lo && wave < 2) {   // first chunk of the rest: waves 0 and 1 walk the hot segment first
+            const int32_t t_lo = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);
+            const int32_t hot0 = __builtin_amdgcn_readfirstlane(ctl[CTL_HOT]);
+            if (wave == 0)
+                hot_walk<T, KC, FAST == 2, 0>(g, run_lo, t_lo, n_hot_blk, hot0, c_base, P, b_u, z, b, alpha, beta1, beta2, k, qs, bis,
+                                              ctl, ebuf, err);
+            else
+                hot_walk<T, KC, FAST == 2, 1>(g, run_lo, t_lo, n_hot_blk, hot0, c_base, P, b_u, z, b, alpha, beta1, beta2, k, qs, bis,
+                                              ctl, ebuf, err);
+        }
+    }
     if constexpr (FASTA) {
-        if (gated && lo == seg_lo) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segments first
+        if (gated && !serial && lo == seg_lo) {   // first chunk of the rest: waves 0 .. n_abuf-1 do the hot segments first
             const int32_t t_lo = __builtin_amdgcn_readfirstlane(g.run_start[run_lo]);   // single-rating runs: rating = t_lo + i
             if (multi)
                 phase_a_gram<KC, true>(g, run_lo, t_lo, c_base, (float *)P, (float *)b_u, (float)b, (float)alpha,
@@ -1226,7 +1508,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         auto index = [&](int32_t jj, RunIdx &x) {
             const int32_t ii = jj < nr ? jj : nr;
             x.j = jj; x.u = rt_u[ii]; x.t0 = rt_t[ii]; x.t1 = rt_t[ii + 1];
-            if constexpr (FASTA) {
+            if constexpr (GATED) {
                 PF_T(i0);
                 const int32_t w = __builtin_amdgcn_readfirstlane(x.u);
                 PF_T(i1);
@@ -1381,7 +1663,7 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
                                               qs, bis, s.err, (int *)(smem + lp.rt_u), (int *)(smem + lp.rt_t),
                                               __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c]),
                                               __builtin_amdgcn_readfirstlane(g.blk_run_ptr[r * g.Gc + c + 1]), n_hot_blk, 0,
-                                              nullptr, 0, 0 PF_PASS);
+                                              nullptr, 0, 0, 0, nullptr PF_PASS);
     stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
 }
 
@@ -1389,12 +1671,17 @@ __global__ __launch_bounds__(1024, WAVES_PER_SIMD(T, KC)) void k_epoch_fixed(Gri
 // WPS = waves per SIMD the kernel is built for: 8 (64 VGPRs) lets two 16-wave workgroups share a CU, 4 (128 VGPRs)
 // is one workgroup per CU without the register squeeze - 3-8% faster whenever the grid has no more stripes than
 // the GPU has CUs (measured: netflix 33.7 -> 32.3 ms, frozen 44.0 -> 40.7 ms), so both are built for k <= 128 fp32.
-template <typename T, int KC, bool STAGE, int FAST, int WPS>
+// HOTK = how this build walks hot segments: 0 item tickets, 1 the matrix-core pipeline (phase_a_gram), 2 the walker
+// (hot_walk).  Separate builds: with both in one kernel the register allocator spills 36 VGPRs in the rest's walk
+// (8 with either alone).
+template <typename T, int KC, bool STAGE, int FAST, int WPS, int HOTK>
 __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alpha,
                                                      T beta1, T beta2, int variant, int k, LdsPlan<T> lp, SchedView s)
 {
     // the hot-item pipeline needs fp32 MFMA, k = 64 / 128 / 256, 128 registers and row buffers in LDS (lp.n_abuf > 0)
-    constexpr bool FASTA = FAST == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && WPS == 4;
+    constexpr bool FASTA = HOTK == 1 && FAST == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && WPS == 4;
+    // the register-resident hot-item walker: every straight-line build with the stripe in LDS and 128 registers
+    constexpr bool SERIAL = HOTK == 2 && FAST != 0 && STAGE && WPS == 4 && KC * sizeof(T) <= 16 && KC != 3;   // a row slot is one 4/8/16-byte load per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *ctl = (int *)(smem + lp.ctl);
     int *tick_done = (int *)(smem + lp.tick);
@@ -1545,13 +1832,14 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                 held = r;
             }
             if (r < 0) break;
-            process_block<T, KC, STAGE, FAST, FASTA>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
+            process_block<T, KC, STAGE, FAST, FASTA, SERIAL>(g, r, c, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k,
                                                      ctl, tick_done, qs, bis, s.err, (int *)(smem + lp.rt_u),
                                                      (int *)(smem + lp.rt_t), __builtin_amdgcn_readfirstlane(rowrun[4 * r]),
                                                      __builtin_amdgcn_readfirstlane(rowrun[4 * r + 1]),
                                                      __builtin_amdgcn_readfirstlane(rowrun[4 * r + 2]),
                                                      __builtin_amdgcn_readfirstlane(rowrun[4 * r + 3]),
-                                                     smem + lp.abuf, lp.abuf_bytes, lp.n_abuf PF_PASS);
+                                                     smem + lp.abuf, lp.abuf_bytes, lp.n_abuf, lp.hot_walker,
+                                                     (T *)(smem + lp.ebuf) PF_PASS);
         }
         stripe_store<T, STAGE>(g, c, Q, b_i, k, qs, bis);
         if (sched_wave) s.col_clock[2 * c + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1599,16 +1887,29 @@ int launch_epochs(mfsgd_grid *G, const GridView &gv, T *P, T *Q, T *b_u, T *b_i,
     constexpr bool can8 = WAVES_PER_SIMD(T, KC) == 8;
     // ... unless the grid has hot segments and their pipeline can run: it needs the 128-register build, and hot segments
     // that go through the tickets cost more than the second workgroup gains
-    const bool pipe = fast == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
+    // hot segments: mode 2 (default) = the register-resident walker for stripes with one hot item (every straight-line
+    // build), the matrix-core pipeline for stripes with several; mode 1 = the pipeline only; mode 0 or hot_bufs 0 = tickets
+    const bool walker = fast != 0 && STAGE && G->info.n_hot > 0 && G->hot_bufs > 0 && G->hot_mode == 2 &&
+                        G->info.n_hot_items == G->info.n_hot_stripes && KC * sizeof(T) <= 16 && KC != 3 &&
+                        (uint64_t)gv.n_users * (uint64_t)k * sizeof(T) < ((uint64_t)1 << 32);   // 32-bit row offsets in the walker
+    const bool pipe = !walker && G->hot_mode >= 1 &&
+                      fast == 1 && STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4) && G->info.n_hot > 0 && G->hot_bufs > 0 &&
                       lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs).n_abuf >= 2;   // one wave alone is no pipeline (ExplicitMF._pipeline_runs applies the same rule)
-    const bool wps8 = can8 && !pipe && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
-    auto kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 4> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 4> : k_epoch_free<T, KC, STAGE, 0, 4>;
+    const bool wps8 = can8 && !pipe && !walker && G->n_cols_nonempty > prop.multiProcessorCount && 2 * (size_t)lp.total <= (size_t)160 * 1024;
+    auto kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 4, 0> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 4, 0> : k_epoch_free<T, KC, STAGE, 0, 4, 0>;
+    if constexpr (STAGE && sizeof(T) == 4 && (KC <= 2 || KC == 4)) {
+        if (pipe) kern = k_epoch_free<T, KC, STAGE, 1, 4, 1>;
+    }
+    if constexpr (STAGE && KC * sizeof(T) <= 16 && KC != 3) {
+        if (walker) kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 4, 2> : k_epoch_free<T, KC, STAGE, 2, 4, 2>;
+    }
     if constexpr (can8) {
-        if (wps8) kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 8> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 8> : k_epoch_free<T, KC, STAGE, 0, 8>;
+        if (wps8) kern = fast == 1 ? k_epoch_free<T, KC, STAGE, 1, 8, 0> : fast == 2 ? k_epoch_free<T, KC, STAGE, 2, 8, 0> : k_epoch_free<T, KC, STAGE, 0, 8, 0>;
     }
     // the hot-item pipeline (phase_a_gram): fp32, k = 64, 128 or 256, the 128-register build, and as many row buffers as
     // the LDS left by the stripe holds (at most G->hot_bufs); without a buffer the hot segments take the ticket path
     if (pipe) lp = lds_plan<T>(gv.ibp, gv.Gr, k, STAGE, dynamic, G->hot_bufs);
+    lp.hot_walker = walker ? 1 : 0;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     if (n_wg <= 0) {
         int per_cu = (int)((size_t)160 * 1024 / std::max<size_t>(lp.total, 1));
@@ -1667,12 +1968,18 @@ int epoch_impl(mfsgd_grid *G, T *P, T *Q, T *b_u, T *b_i, T b, const T *z, T alp
                                                schedule, seed, n_wg, waves, order_log, st)                            \
                  : launch_epochs<T, KC_, false>(G, gv, P, Q, b_u, b_i, b, z, alpha, beta1, beta2, variant, k, iters,  \
                                                 schedule, seed, n_wg, waves, order_log, st)
+#ifdef MFSGD_DEV_KC2      // development builds: only the float32 k = 65..128 kernels (a tenth of the compile time)
+    if constexpr (sizeof(T) == 4) { if (kc == 2) { MF_GO(2); } }
+    mfsgd_set_error("epoch: development build (MFSGD_DEV_KC2) has float32 k = 65..128 only");
+    return MFSGD_ERR_UNSUPPORTED;
+#else
     switch (kc) {
         case 1: MF_GO(1);
         case 2: MF_GO(2);
         case 3: MF_GO(3);
         default: MF_GO(4);
     }
+#endif
 #undef MF_GO
 }
 
@@ -1729,6 +2036,14 @@ int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n)
     MF_ARG(g, "grid_set_hot_buffers: null grid");
     MF_ARG(n >= 0 && n <= PA_MAX_BUFS, "grid_set_hot_buffers: n=%d outside [0,%d]", n, PA_MAX_BUFS);
     g->hot_bufs = n;
+    return MFSGD_OK;
+}
+
+int mfsgd_grid_set_hot_mode(mfsgd_grid *g, int32_t mode)
+{
+    MF_ARG(g, "grid_set_hot_mode: null grid");
+    MF_ARG(mode >= 0 && mode <= 2, "grid_set_hot_mode: mode=%d outside [0,2]", mode);
+    g->hot_mode = mode;
     return MFSGD_OK;
 }
 
