@@ -261,10 +261,11 @@ int mfsgd_hip_epoch_f64(mfsgd_grid *g, int32_t k, double *P, double *Q, double *
  * type == 'item', :131 / :142) solves (F^T F + lambda (n_r + 1) I) x = F^T v with F = fixed[col_inds of r]
  * (:133-139) and writes x to latent[r]; a row without entries gets zeros.  `fixed` is only read (the reference
  * copies it, :127).  `fixed` has n_cols rows, the CSR nnz entries: the kernel checks every row range and column
- * index against them and reports a CSR that does not fit instead of reading outside the arrays.  k <= 128 (the
- * k x k normal matrix of a row lives in the registers of one 256-thread workgroup, 64 entries per thread at k = 128;
- * BASELINE config 5's k = 256 would need 256 per thread and is refused with MFSGD_ERR_ARG - ALS is a "next" row of
- * SURVEY.md 8(f), the reference's own default is k = 40, ALSRecommender.py:33),
+ * index against them and reports a CSR that does not fit instead of reading outside the arrays.  k <= 256 (the
+ * reference has no limit; BASELINE config 5 runs k = 256): up to k = 128 the k x k normal matrix of a row lives in the
+ * registers of one 256-thread workgroup (64 entries per thread at k = 128), above in those of a 1024-thread workgroup
+ * with the factor's lower triangle packed in LDS (fp32 to k = 256, fp64 to k = 192) or in a slab of device memory the
+ * call allocates per workgroup (fp64, 193 <= k <= 256); k > 256 is refused with MFSGD_ERR_ARG,
  * lambda > 0 (the reference's defaults 0.0 make its solve singular for short rows).  Synchronises the stream
  * before it returns (a broken CSR or a non-positive pivot is reported as an error). */
 int mfsgd_hip_als_step_f32(float *latent, const float *fixed, const int64_t *row_ptrs, const int32_t *col_inds,

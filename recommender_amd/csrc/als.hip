@@ -21,6 +21,10 @@
 //      barrier - and the LDS copy of the columns is the factor the substitution needs.
 //   3. Back substitution by wave 0 on the LDS copy (column reads at an odd stride: conflict-free).
 // fp32 and fp64 share the code (the reference is float64; fp64 is what the 1e-9 parity test runs).
+// k > 128 (BASELINE config 5's k = 256; the reference has no limit, ALSRecommender.py:118-155): the same scheme on a
+// 32 x 32 arrangement (1024 threads, at most 8 x 8 entries per thread), vector Gram, and the factor stored PACKED (lower
+// triangle only, k (k + 1) / 2 entries): 132 KB of LDS in fp32 at k = 256; in fp64 it does not fit a CU's LDS above
+// k = 176 and lives in a per-workgroup slab of device memory instead (the workgroup's own L1/L2-resident scratch).
 #include "common.h"
 #include <algorithm>
 
@@ -29,9 +33,7 @@ namespace {
 #ifndef MFSGD_ALS_CH
 #define MFSGD_ALS_CH 16
 #endif
-constexpr int ALS_CH = MFSGD_ALS_CH;   // factor rows gathered per step (a multiple of 16)
-constexpr int ALS_RPT = ALS_CH / 16;   // of which every thread row of the 16 x 16 arrangement fetches this many
-constexpr int ALS_THREADS = 256;
+constexpr int ALS_RPT = MFSGD_ALS_CH / 16;   // factor rows every thread row of the G x G arrangement fetches per step
 #ifndef MFSGD_ALS_EXP
 #define MFSGD_ALS_EXP 0   // timing experiments (results wrong on purpose): 1 = no elimination, 2 = no substitution
 #endif
@@ -40,18 +42,21 @@ struct AlsPlan {                 // byte offsets in dynamic LDS (multiples of 16
     uint32_t chunk, cvals, lmat, zfin, ctl, total;
 };
 
-template <typename T> AlsPlan als_plan(int k, int ts)
+// g = side of the thread arrangement (16 or 32); packed = the factor keeps its lower triangle only; factor_in_lds = false:
+// the factor lives in device memory (als_impl allocates the slabs) and only the gather buffers are in LDS
+template <typename T> AlsPlan als_plan(int k, int ts, int g = 16, bool packed = false, bool factor_in_lds = true)
 {
     auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t kp = (size_t)ts * 16, ld = kp + 1;
+    const size_t kp = (size_t)ts * g, ld = kp + 1, ch = (size_t)g * ALS_RPT;
     AlsPlan p{};
     size_t o = 0;
     // the gather buffers are only alive during the Gram phase, the factor only after it: they share one region
-    const size_t stage = up(2 * ALS_CH * kp * sizeof(T)) + up(2 * ALS_CH * sizeof(T));
+    const size_t stage = up(2 * ch * kp * sizeof(T)) + up(2 * ch * sizeof(T));
+    const size_t factor = !factor_in_lds ? 0 : packed ? kp * (kp + 1) / 2 * sizeof(T) : kp * ld * sizeof(T);
     p.chunk = (uint32_t)o;
-    p.cvals = (uint32_t)(o + up(2 * ALS_CH * kp * sizeof(T)));
+    p.cvals = (uint32_t)(o + up(2 * ch * kp * sizeof(T)));
     p.lmat = (uint32_t)o;
-    o = up(o + std::max(stage, kp * ld * sizeof(T)));   // kp rows: the matrix-core path parks the whole padded Gram matrix here
+    o = up(o + std::max(stage, factor));   // kp rows: the matrix-core path parks the whole padded Gram matrix here
     p.zfin = (uint32_t)o;  o = up(o + 2 * kp * sizeof(T));   // eliminated right-hand side, reciprocal pivots
     p.ctl = (uint32_t)o;   o = up(o + 16);
     p.total = (uint32_t)o;
@@ -81,23 +86,39 @@ __device__ __forceinline__ double pivot_inv(double d) { return 1.0 / d; }
 // tiles, the tiles on and below the diagonal dealt round-robin to the four waves, and handed over to the cyclic
 // register layout of the elimination through LDS.  Otherwise (fp64, or k <= 64 where the padding to 32 costs more
 // than it saves) the threads accumulate their own entries with vector FMAs.
-template <typename T, int TS, bool MFMA>
-__global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent, const T *__restrict__ fixed,
+// G = side of the thread arrangement: 16 (256 threads, k <= 128) or 32 (1024 threads, k <= 256: PACKED factor, in LDS or -
+// GLOBAL_L - in the workgroup's slab of `lscratch`)
+template <typename T, int G, int TS, bool MFMA, bool PACKED, bool GLOBAL_L>
+__global__ __launch_bounds__(G * G) void k_als_rows(T *__restrict__ latent, const T *__restrict__ fixed,
                                                           const int64_t *__restrict__ row_ptrs,
                                                           const int32_t *__restrict__ col_inds,
                                                           const T *__restrict__ vals, int64_t n_rows, int64_t n_cols,
                                                           int64_t nnz, int k, T lambda, int32_t *next_row,
-                                                          int32_t *err, AlsPlan lp)
+                                                          int32_t *err, AlsPlan lp, T *lscratch)
 {
+    static_assert(G == 16 || G == 32, "16 x 16 or 32 x 32 threads");
+    static_assert(!MFMA || (G == 16 && !PACKED && !GLOBAL_L), "the matrix-core Gram path is the 16 x 16 kernel's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KP = 16 * TS, LD = KP + 1;
+    constexpr int ALS_THREADS = G * G, ALS_CH = G * ALS_RPT;
+    constexpr int KP = G * TS, LD = KP + 1;
     T *chunk = (T *)(smem + lp.chunk);    // [2][ALS_CH][KP], columns k..KP-1 are zero
     T *cvals = (T *)(smem + lp.cvals);    // [2][ALS_CH]
-    T *lmat = (T *)(smem + lp.lmat);      // [k][LD]: row j holds column j of the factor, unscaled; [j][j] = d_j
+    // the factor: column j, unscaled, entry (j, j) = d_j.  Full layout: [k][LD], row j holds column j.  PACKED: column j
+    // holds its rows j .. KP-1 only, the columns back to back (lidx)
+    T *lmat;
+    if constexpr (GLOBAL_L) lmat = lscratch + (size_t)blockIdx.x * ((size_t)KP * (KP + 1) / 2);
+    else lmat = (T *)(smem + lp.lmat);
+    auto lidx = [](int j, int i) { return PACKED ? j * KP - j * (j - 1) / 2 + (i - j) : j * LD + i; };   // column j, row i (>= j)
     T *zfin = (T *)(smem + lp.zfin);      // [KP]: eliminated right-hand side
     T *dinv = zfin + KP;                  // [KP]: 1 / d_j
     int *ctl = (int *)(smem + lp.ctl);
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, ty = tid / G, tx = tid % G;
+    // a barrier that also orders the workgroup's device-memory traffic when the factor lives there
+    auto sync = [] {
+        if constexpr (GLOBAL_L) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if constexpr (GLOBAL_L) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     for (;;) {
         __syncthreads();                  // the previous row's LDS is no longer read
         if (tid == 0) ctl[0] = atomicAdd(next_row, 1);
@@ -124,14 +145,14 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         auto fetch = [&](int64_t base) {          // thread row ty of the 16 x 16 arrangement fetches factor rows ty, ty + 16, ..
 #pragma unroll
             for (int q = 0; q < ALS_RPT; ++q) {
-                const int64_t t = base + ty + 16 * q;
+                const int64_t t = base + ty + G * q;
                 bool live = t < hi;
                 const int64_t col = live ? col_inds[t] : 0;
                 if (live && (col < 0 || col >= n_cols)) { live = false; atomicOr(err, 2); }   // never read outside `fixed`
                 const T *src = fixed + (live ? col : 0) * k;
 #pragma unroll
                 for (int b = 0; b < TS; ++b) {
-                    const int c = tx + 16 * b;
+                    const int c = tx + G * b;
                     pre[q][b] = (live && c < k) ? src[c] : (T)0;
                 }
                 prev[q] = (live && tx == 0) ? vals[t] : (T)0;
@@ -141,8 +162,8 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
             for (int q = 0; q < ALS_RPT; ++q) {
 #pragma unroll
-                for (int b = 0; b < TS; ++b) chunk[buf * (ALS_CH * KP) + (ty + 16 * q) * KP + tx + 16 * b] = pre[q][b];
-                if (tx == 0) cvals[buf * ALS_CH + ty + 16 * q] = prev[q];
+                for (int b = 0; b < TS; ++b) chunk[buf * (ALS_CH * KP) + (ty + G * q) * KP + tx + G * b] = pre[q][b];
+                if (tx == 0) cvals[buf * ALS_CH + ty + G * q] = prev[q];
             }
         };
         fetch(lo);
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
             for (int m = 0; m < ALS_CH; ++m) {
                 T ai[TS], al[TS];
 #pragma unroll
-                for (int a = 0; a < TS; ++a) { ai[a] = ch[m * KP + ty + 16 * a]; al[a] = ch[m * KP + tx + 16 * a]; }
+                for (int a = 0; a < TS; ++a) { ai[a] = ch[m * KP + ty + G * a]; al[a] = ch[m * KP + tx + G * a]; }
 #pragma unroll
                 for (int a = 0; a < TS; ++a)
 #pragma unroll
@@ -245,22 +266,26 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
         bool bad = false;
 #pragma unroll
         for (int jb = 0; jb < TS; ++jb) {
-            for (int jt = 0; jt < 16; ++jt) {
-                const int j = 16 * jb + jt;
+            for (int jt = 0; jt < G; ++jt) {
+                const int j = G * jb + jt;
                 if (j >= ((MFSGD_ALS_EXP & 1) ? 0 : k)) break;
                 if (tx == jt) {
 #pragma unroll
-                    for (int a = jb; a < TS; ++a) lmat[j * LD + ty + 16 * a] = acc[a][jb];
+                    for (int a = jb; a < TS; ++a)
+                        if (!PACKED || ty + G * a >= j) lmat[lidx(j, ty + G * a)] = acc[a][jb];   // packed columns start at their diagonal
                     if (ty == 0) zfin[j] = zacc[jb];
                 }
-                __syncthreads();
-                const T d = lmat[j * LD + j];
+                if constexpr (PACKED) sync();
+                else __syncthreads();
+                const T d = lmat[lidx(j, j)];
                 bad = bad || !(d > 0);
                 const T inv = pivot_inv(d);
                 if (tid == 0) dinv[j] = inv;
                 T ci[TS], cl[TS];
+                // rows above the diagonal (inside the panel's first tile) are finished: whatever is read for them - in the
+                // packed layout the tail of the previous column - only reaches entries that are never read again
 #pragma unroll
-                for (int a = jb; a < TS; ++a) { ci[a] = lmat[j * LD + ty + 16 * a] * inv; cl[a] = lmat[j * LD + tx + 16 * a]; }
+                for (int a = jb; a < TS; ++a) { ci[a] = lmat[lidx(j, ty + G * a)] * inv; cl[a] = lmat[lidx(j, tx + G * a)]; }
                 // inside the panel's own tiles, entries in rows or columns <= j are finished and never read again, so
                 // the update runs unguarded there; the right-hand side is live and is guarded
 #pragma unroll
@@ -271,12 +296,13 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
                     const T zj = zfin[j] * inv;
 #pragma unroll
                     for (int b = jb; b < TS; ++b)
-                        if (tx + 16 * b > j) zacc[b] -= cl[b] * zj;
+                        if (tx + G * b > j) zacc[b] -= cl[b] * zj;
                 }
             }
         }
         if (bad && tid == 0) atomicOr(err, 1);
-        __syncthreads();
+        if constexpr (PACKED) sync();
+        else __syncthreads();
         // ---- 3. back substitution: x_j = w_j / d_j, then w_l -= A[j][l] x_j for l < j (A[j][l] = column l at row j)
         if (tid < 64) {
             // One wave, k dependent steps: everything a step needs except x_j itself is fetched four steps ahead
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(ALS_THREADS) void k_als_rows(T *__restrict__ latent
 #pragma unroll
                 for (int c = 0; c < WC; ++c) {
                     const int l = tid + 64 * c;
-                    out[c] = (j >= 0 && l < j) ? lmat[l * LD + j] : (T)0;
+                    out[c] = (j >= 0 && l < j) ? lmat[lidx(l, j)] : (T)0;
                 }
             };
             constexpr int AHEAD = 4;                      // columns in flight (LDS latency / step time)
@@ -339,42 +365,67 @@ int als_impl(T *latent, const T *fixed, const int64_t *row_ptrs, const int32_t *
     MF_ARG(latent && fixed && row_ptrs, "als_step: null pointer");
     MF_ARG(n_cols >= 1 && nnz >= 0 && (nnz == 0 || (col_inds && vals)), "als_step: n_cols=%lld, nnz=%lld or null CSR arrays",
            (long long)n_cols, (long long)nnz);
-    MF_ARG(k >= 1 && k <= 128, "als_step: k=%d outside [1,128]", k);
+    MF_ARG(k >= 1 && k <= 256, "als_step: k=%d outside [1,256]", k);
     MF_ARG(lambda > 0, "als_step: lambda must be positive (the normal matrix has to be positive definite)");
     hipStream_t st = as_stream(stream);
     int32_t *work = nullptr;             // [0] next row, [1] error flag
     MF_HIP(hipMalloc((void **)&work, 16));
-    struct Guard { int32_t *p; ~Guard() { (void)hipFree(p); } } guard{work};
+    struct Guard { void *p; ~Guard() { if (p) (void)hipFree(p); } } guard{work};
     MF_HIP(hipMemsetAsync(work, 0, 16, st));
-    // fp32 above k = 64: Gram on the matrix cores, which wants the padded size to be a multiple of 32
-    const bool mfma = sizeof(T) == 4 && k > 64;
-    const int ts = mfma ? 2 * ((k + 31) / 32) : (k + 15) / 16;
-    const AlsPlan lp = als_plan<T>(k, ts);
     int dev = 0, n_cu = 256;
     MF_HIP(hipGetDevice(&dev));
     MF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lp.total)));
-    const int64_t n_wg = std::min<int64_t>(n_rows, (int64_t)n_cu * per_cu);
-#define MF_ALS(TS_, M_)                                                                                               \
+    constexpr size_t LDS_BYTES = (size_t)160 * 1024;
+#define MF_ALS_GO(G_, TS_, M_, PK_, GL_)                                                                              \
     {                                                                                                                 \
-        auto kern = k_als_rows<T, TS_, M_>;                                                                           \
+        auto kern = k_als_rows<T, G_, TS_, M_, PK_, GL_>;                                                             \
         MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));   \
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(ALS_THREADS), lp.total, st, latent, fixed, row_ptrs,      \
-                           col_inds, vals, n_rows, n_cols, nnz, (int)k, lambda, work, work + 1, lp);                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(G_ * G_), lp.total, st, latent, fixed, row_ptrs,          \
+                           col_inds, vals, n_rows, n_cols, nnz, (int)k, lambda, work, work + 1, lp, lscratch);        \
         break;                                                                                                        \
     }
-    if constexpr (sizeof(T) == 4) {
-        switch (mfma ? 100 + ts : ts) {
-            case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
-            case 106: MF_ALS(6, true) case 108: MF_ALS(8, true)
+    T *lscratch = nullptr;
+    Guard guard2{nullptr};
+    if (k <= 128) {
+        // fp32 above k = 64: Gram on the matrix cores, which wants the padded size to be a multiple of 32
+        const bool mfma = sizeof(T) == 4 && k > 64;
+        const int ts = mfma ? 2 * ((k + 31) / 32) : (k + 15) / 16;
+        const AlsPlan lp = als_plan<T>(k, ts);
+        const int per_cu = std::max(1, std::min(8, (int)(LDS_BYTES / lp.total)));
+        const int64_t n_wg = std::min<int64_t>(n_rows, (int64_t)n_cu * per_cu);
+#define MF_ALS(TS_, M_) MF_ALS_GO(16, TS_, M_, false, false)
+        if constexpr (sizeof(T) == 4) {
+            switch (mfma ? 100 + ts : ts) {
+                case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
+                case 106: MF_ALS(6, true) case 108: MF_ALS(8, true)
+            }
+        } else {
+            switch (ts) {
+                case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
+                case 5: MF_ALS(5, false) case 6: MF_ALS(6, false) case 7: MF_ALS(7, false) case 8: MF_ALS(8, false)
+            }
         }
-    } else {
-        switch (ts) {
-            case 1: MF_ALS(1, false) case 2: MF_ALS(2, false) case 3: MF_ALS(3, false) case 4: MF_ALS(4, false)
-            case 5: MF_ALS(5, false) case 6: MF_ALS(6, false) case 7: MF_ALS(7, false) case 8: MF_ALS(8, false)
-        }
-    }
 #undef MF_ALS
+    } else {
+        // 129 <= k <= 256: 32 x 32 threads, the factor packed; in LDS when its triangle fits next to nothing else (the
+        // gather buffers share its region), else in a slab of device memory per workgroup
+        const int ts = (k + 31) / 32;
+        const bool in_lds = als_plan<T>(k, ts, 32, true, true).total <= LDS_BYTES;
+        const AlsPlan lp = als_plan<T>(k, ts, 32, true, in_lds);
+        MF_ARG(lp.total <= LDS_BYTES, "als_step: k=%d does not fit", k);
+        const int64_t n_wg = std::min<int64_t>(n_rows, (int64_t)n_cu);   // 1024 threads: one workgroup per CU
+        if (!in_lds) {
+            const size_t slab = (size_t)(32 * ts) * (32 * ts + 1) / 2;
+            MF_HIP(hipMalloc((void **)&lscratch, (size_t)n_wg * slab * sizeof(T)));
+            guard2.p = lscratch;
+        }
+#define MF_ALS(TS_) { if (in_lds) MF_ALS_GO(32, TS_, false, true, false) else MF_ALS_GO(32, TS_, false, true, true) }
+        switch (ts) {
+            case 5: MF_ALS(5) break; case 6: MF_ALS(6) break; case 7: MF_ALS(7) break; case 8: MF_ALS(8) break;
+        }
+#undef MF_ALS
+    }
+#undef MF_ALS_GO
     MF_LAUNCH_CHECK();
     int32_t h[2] = {0, 0};
     MF_HIP(hipMemcpyAsync(h, work, 8, hipMemcpyDeviceToHost, st));

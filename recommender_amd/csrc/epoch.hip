@@ -1474,6 +1474,11 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             else
                 hot_walk<T, KC, FAST == 2, 1>(g, run_lo, t_lo, n_hot_blk, hot0, c_base, P, b_u, z, b, alpha, beta1, beta2, k, qs, bis,
                                               ctl, ebuf, err);
+#ifdef MFSGD_PROF
+            PF_T(hw1);
+            if (wave == 1) { PF_ADD(31, b0, hw1); PF_INC(PF_ISSUE, 1); PF_INC(27, n_hot_blk); }   // block start -> segment published; links
+            else PF_ADD(24, bs, hw1);                                                            // the chain wave's time in the segment
+#endif
         }
     }
     if constexpr (FASTA) {

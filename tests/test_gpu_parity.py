@@ -678,19 +678,22 @@ def test_als_step_vs_reference(ra, k, dt, tol):
     assert abs(m.predict(3, 5) - m.user_vecs[3].dot(m.item_vecs[5])) < 1e-12
 
 
-@pytest.mark.parametrize("k,U,I,n", [(128, 300, 4000, 60000), (100, 500, 700, 30000), (80, 400, 600, 30000),
+@pytest.mark.parametrize("k,U,I,n", [(256, 300, 4000, 60000), (250, 700, 900, 40000), (224, 200, 500, 20000),
+                                     (192, 300, 500, 20000), (160, 300, 400, 20000), (129, 150, 300, 8000),
+                                     (128, 300, 4000, 60000), (100, 500, 700, 30000), (80, 400, 600, 30000),
                                      (65, 100, 300, 8000), (64, 300, 300, 20000), (16, 2000, 50, 20000), (1, 40, 30, 300)])
 def test_als_step_vs_oracle_shapes(ra, orc, k, U, I, n):
-    """Sizes the golden does not cover: k = 128 (the largest), k not a multiple of 16, both matrix-core variants of
-    the fp32 kernel (65 <= k <= 96 and 97 <= k <= 128) and the largest vector one (k = 64), rows of thousands of
-    entries, empty rows, k = 1.  fp64 against the fp64 oracle to 1e-9; fp32 against the fp64 oracle to 1e-3 (the normal
-    equations square the conditioning)."""
+    """Sizes the golden does not cover: k = 256 (the largest, BASELINE config 5's k) and the other 32 x 32-thread kernels
+    (129 <= k <= 256: packed factor in LDS, or - fp64 above k = 192 - in device memory), k = 128, k not a multiple of 16,
+    both matrix-core variants of the fp32 kernel (65 <= k <= 96 and 97 <= k <= 128) and the largest vector one (k = 64),
+    rows of thousands of entries, empty rows, k = 1.  fp64 against the fp64 oracle to 1e-9; fp32 against the fp64 oracle
+    to 1e-3 (the normal equations square the conditioning)."""
     import torch
     from recommender_amd import _abi
     rng = np.random.default_rng(k + U)
     s = _synthetic(rng, U, I, n)
     s = s[s[:, 0] % 17 != 3]                                        # users without ratings
-    if k == 128:                                                    # one user who rated 3000 items
+    if k in (128, 256):                                             # one user who rated 3000 items
         extra = np.column_stack([np.full(3000, 5), rng.permutation(I)[:3000], rng.integers(1, 11, 3000)])
         s = np.concatenate([s[s[:, 0] != 5], extra]).astype(np.int32)
     rp, ci, v = _als_csr(s[:, 0], s[:, 1], s[:, 2].astype(np.float64), U)
@@ -718,7 +721,7 @@ def test_als_step_rejects_bad_arguments(ra):
     with pytest.raises(Exception, match="positive"):
         ALS.als_step(np.zeros((2, 4)), np.ones((2, 4)), R, 0.0, "user")       # the reference's default: singular
     with pytest.raises(Exception, match="k="):
-        ALS.als_step(np.zeros((2, 129)), np.ones((2, 129)), R, 0.1, "user")
+        ALS.als_step(np.zeros((2, 257)), np.ones((2, 257)), R, 0.1, "user")
     with pytest.raises(ValueError):
         ALS.als_step(np.zeros((3, 4)), np.ones((2, 4)), R, 0.1, "user")
     bad = CSRView(np.array([0, 1, 2], np.int64), np.array([0, 9], np.int32), np.array([3.0, 4.0]), 2, 2)
