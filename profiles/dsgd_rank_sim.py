@@ -29,7 +29,7 @@ du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
 di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
 plan0 = dsgd.DSGDPlan(U, I, world, ubp, ibp)
 rows = max(1, -(-(plan0.user_range(0)[1] - plan0.user_range(0)[0]) // ubp))
-cost = item_costs(di, rows, plan0.Gc, dsgd.pipeline_fits(I, ibp, rows, k, hot_buffers), 1)
+cost = item_costs(di, rows, plan0.Gc, dsgd.pipeline_fits(I, ibp, rows, k, hot_buffers), 1, walker=True)
 rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
 cp = torch.from_numpy(interleave_stripes(balanced_permutation(di, ibp, cost), ibp, world).astype(np.int32)).cuda()
 _abi.check(_abi.lib().mfsgd_hip_remap(_abi.ptr(train), n, 3, _abi.ptr(rp), _abi.ptr(cp), U, I, None))

@@ -93,13 +93,16 @@ def _balanced_by_cost(deg, cost, width):
 
 
 CHAIN_RATING_COST = 5.0     # a rating of a stripe's most rated item on the ticket path against any other rating there
-HOT_RATING_COST = 0.8       # a rating on the hot-item pipeline against one on the ticket path, as the dealing should count
+HOT_RATING_COST = 0.8       # a rating on the matrix-core pipeline against one on the ticket path, as the dealing should count
                             # it (netflix shape, k = 128, swept 0.25 .. 1.0: 25.4 ms per epoch at 0.25, 24.1 at 0.7 - 0.85,
                             # 24.4 at 1.0; the pipeline's own time per rating is a third of the ticket path's, but the
                             # users of a hot segment hold their other runs back until the pipeline has passed them)
+WALKER_RATING_COST = 0.3    # the same for the hot-item walker (two waves instead of six, the frontier moves every 64 links):
+                            # netflix shape, k = 128: 21.0 ms per epoch at 0.1, 21.1 at 0.2, 21.3 at 0.3, 21.6 at 0.5, 22.1 at
+                            # 0.8; ML-25M shape 9.05 at 0.1, 8.93 at 0.3, 8.79 at 0.8; frozen term 28.2 at 0.3, 28.1 at 0.8
 
 
-def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64):
+def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64, walker=False):
     """What an item's ratings cost in time, for dealing items to stripes (balanced_permutation): its degree, except for
     the items that lead their stripes.  Where the hot-item pipeline runs, the stripes' hot items - the hot_items * Gc
     most rated ones, as far as they qualify (ExplicitMF.build_grid) - count HOT_RATING_COST per rating; through the tickets
@@ -113,7 +116,7 @@ def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64)
     if pipeline_runs and hot_items > 0:
         top = top[:hot_items * Gc]
         top = top[deg[top] >= max(256, hot_min * Gr)]
-        w = HOT_RATING_COST if weight is None else float(weight)
+        w = (WALKER_RATING_COST if walker else HOT_RATING_COST) if weight is None else float(weight)
     else:
         top = top[:Gc]
         w = CHAIN_RATING_COST if weight is None else float(weight)
@@ -654,7 +657,8 @@ class ExplicitMF(Recommender):
         du = torch.bincount(self._d_samples[:, 0].long(), minlength=self.n_users).cpu().numpy()
         di = torch.bincount(self._d_samples[:, 1].long(), minlength=self.n_items).cpu().numpy()
         Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
-        cost = item_costs(di, Gr, Gc, self._hot_path_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min)
+        cost = item_costs(di, Gr, Gc, self._hot_path_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min,
+                          walker=self._walker_runs(Gr, Gc))
         self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):

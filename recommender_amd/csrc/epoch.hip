@@ -1130,11 +1130,16 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 // stripes fill the LDS (ML-25M shape) and the matrix-core pipeline has no room for its row buffers.
 // One hot item per stripe (the default); stripes with several hot items go through phase_a_gram or the tickets.
 // The rest of the block runs meanwhile on the other waves, the runs of the segment's users behind the frontier word
-// (CTL_FMIN), which this wave raises ONCE, when the segment is through and its row stores have drained (raising it
-// chunk by chunk would mean draining the ring of requested rows every 64 links; the segment takes a fraction of the
-// time the other waves need for the runs that wait for nothing).
+// (CTL_FMIN), which the apply wave raises after every chunk of 64 links, once the chunk's row stores have drained (one
+// drain of its ring of requested rows per chunk: the apply wave can afford it, the chain wave never drains).
 #ifndef MFSGD_HOT_RING_REGS
-#define MFSGD_HOT_RING_REGS 32
+#define MFSGD_HOT_RING_REGS 32   // 64 (a ring of 32 rows at k = 128): netflix shape 21.6 ms per epoch against 21.3
+#endif
+#ifndef MFSGD_WALK_FRONT
+// the walker's apply wave publishes the user frontier after every chunk of 64 links (0: once, at the end of the segment:
+// netflix shape 24.1 ms per epoch against 22.1, frozen 31.2 against 28.1, ML-25M 9.22 against 8.79; 2: every 32 links:
+// netflix 21.5 against 21.3, ML-25M 8.66 against 8.79)
+#define MFSGD_WALK_FRONT 1
 #endif
 template <typename T, int KC, bool HASZ> struct HotRing {   // register slots: MFSGD_HOT_RING_REGS VGPRs of rows at most, 32 slots at most
     static constexpr int regs = KC * (HASZ ? 2 : 1) * (int)(sizeof(T) / 4);
@@ -1339,6 +1344,15 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
                     vm_store_so(out, P, (uint32_t)__builtin_amdgcn_readlane(offA, li) + lane_off);
                 }
             }
+#if MFSGD_WALK_FRONT >= 2
+            if constexpr (ROLE == 1) {
+                if (li == 31 && nb > 32) {   // half-chunk publish (see the end of the chunk)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int32_t half_user = __builtin_amdgcn_readlane(ujA, 31);
+                    __hip_atomic_store(sink_ptr(&ctl[CTL_FMIN], ctl, lane), half_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#endif
             // the slot is free: request the row of the link HOT_RING further on
             const uint32_t ro = (uint32_t)(li + DD < 64 ? __builtin_amdgcn_readlane(offA, (li + DD) & 63)
                                                         : __builtin_amdgcn_readlane(offB, (li + DD) & 63)) + lane_off;
@@ -1351,6 +1365,19 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
         } else {
             // the users' biases (numba_methods.py:19); the error buffer is free again
             if (lane < nb) untracked_store(&b_u[ujA], buA + alpha * (evec - beta1 * buA));
+#if MFSGD_WALK_FRONT
+            // The chunk's users are done once these stores are: the frontier the gated rest waits behind moves up chunk by
+            // chunk.  That costs this wave one drain of its ring per 64 links (the rows requested for the next chunk land
+            // meanwhile; the chain wave, a chunk or more ahead, is not held up), and lets the runs of the segment's users
+            // start while the segment is still being walked.
+            if (nb > 64) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int32_t last_user = __builtin_amdgcn_readlane(ujA, 63);
+                __hip_atomic_store(sink_ptr(&ctl[CTL_FUSER], ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                LDS_RELEASE();
+                __hip_atomic_store(sink_ptr(&ctl[CTL_FMIN], ctl, lane), last_user, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#endif
             __hip_atomic_store(sink_ptr(&ctl[CTL_FRONT], ctl, lane), chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // The metadata moves up one chunk.  Everything copied here was requested at least a chunk ago - before ring rows

@@ -6,18 +6,16 @@
 // implicit term) are produced tile by tile on the matrix cores and reduced to a top-N on the fly - the
 // users x items score matrix (34 GB for the netflix shape) is never written.
 //
-// Layout of one workgroup (4 waves; 2 waves for k > 200, where four user tiles plus the item chunks no longer fit the
-// 160 KB of LDS): each wave owns 32 users (their factor rows sit in LDS, padded against bank
-// conflicts), all four walk the same 32-item chunks of Q, staged once per workgroup in LDS (double-buffered).
-// Per chunk a wave computes the 32x32 tile  S^T = Q_chunk . P_tile^T  with v_mfma_f32_32x32x2_f32: with items as
-// MFMA rows and users as MFMA columns a lane ends up holding 16 candidate items of ONE user (its column), so the
-// running top-N is private to a lane (registers); the two lanes of a user are merged at the end.
+// Layout of one workgroup (4 waves): each wave owns 32 users, whose factor rows it keeps in registers; all four walk
+// the same 64-item chunks of Q, staged once per workgroup in LDS (double-buffered).  Per 32-item tile a wave computes
+// S^T = Q_tile . P_tile^T  with v_mfma_f32_32x32x2_f32: with items as MFMA rows and users as MFMA columns a lane ends
+// up holding 16 candidate items of ONE user (its column), so the running top-N is private to a lane (registers); the
+// two lanes of a user are merged at the end.
 #include <algorithm>
 #include "common.h"
 
 namespace {
 
-// waves per workgroup = user tiles per workgroup: a template parameter W (4 up to k = 200, 2 up to k = 256)
 constexpr int TN_TILE = 32;     // users per wave, items per chunk
 constexpr int TN_MAX = 16;      // largest N
 
@@ -40,94 +38,72 @@ __device__ __forceinline__ void insert_top(float (&sc)[N], int32_t (&id)[N], flo
     }
 }
 
-template <int N, int TN_WAVES>
-__global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict__ P, const float *__restrict__ Q,
-                                                        const float *__restrict__ b_u, const float *__restrict__ b_i,
-                                                        float b, const int32_t *__restrict__ users, int64_t n_batch,
-                                                        int64_t n_items, int k, int kpad, int with_bias,
-                                                        int32_t *__restrict__ out_items, float *__restrict__ out_scores)
+// KP = k rounded up to a multiple of 32 (zero columns).  One workgroup = 4 waves = 4 x 32 users.
+//  * The users' rows live in REGISTERS for the whole kernel: lane (col, kh) holds P[user col][2 j + kh], j < KP / 2 -
+//    exactly the B operand of MFMA j - so the multiply reads only the item operand from LDS (round 2 kept the user tiles
+//    in LDS: two LDS reads per MFMA, 66 KB of the CU's LDS, one workgroup per CU).
+//  * A step takes 64 items: two 32-item tiles with independent accumulators, their MFMAs interleaved (one wave has two
+//    dependent chains in flight instead of one; the user operand is shared), one barrier per 64 items.
+//  * The item chunks are staged once per workgroup, HBM -> registers before the multiply of the previous step and
+//    registers -> LDS after it.  LDS: 2 x 64 x (KP + 1) floats = 66 KB at k = 128 (two workgroups per CU: two waves per
+//    SIMD), 132 KB at k = 256.
+template <int N, int KP>
+__global__ __launch_bounds__(256, KP <= 128 ? 2 : 1) void k_topn(const float *__restrict__ P, const float *__restrict__ Q,
+                                                                const float *__restrict__ b_u, const float *__restrict__ b_i,
+                                                                float b, const int32_t *__restrict__ users, int64_t n_batch,
+                                                                int64_t n_items, int k, int with_bias,
+                                                                int32_t *__restrict__ out_items, float *__restrict__ out_scores)
 {
+    constexpr int W = 4, CH = 2 * TN_TILE, LD = KP + 1;   // LD odd: a column walk over 32 items hits 32 banks
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *qc = lds;                       // item chunks [2][CH][LD]
+    float *bc = qc + 2 * CH * LD;          // their biases [2][CH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ld = kpad + 1;                           // row stride in LDS: odd, so a column walk hits 32 banks
-    float *pt = lds + (size_t)wave * TN_TILE * ld;     // this wave's user tile [32][ld]
-    float *qc = lds + (size_t)TN_WAVES * TN_TILE * ld; // item chunks [2][32][ld]
-    float *bc = qc + (size_t)2 * TN_TILE * ld;         // item biases of the chunks [2][32]
-    const int64_t u0 = ((int64_t)blockIdx.x * TN_WAVES + wave) * TN_TILE;
+    const int col = lane & 31, kh = lane >> 5;          // MFMA operand coordinates of this lane
+    const int64_t u0 = ((int64_t)blockIdx.x * W + wave) * TN_TILE;
+    const bool live_u = u0 + col < n_batch;
 
-    // user tile -> LDS (rows beyond the batch and columns beyond k are zero)
-    for (int e = lane; e < TN_TILE * kpad; e += 64) {
-        const int r = e / kpad, f = e - r * kpad;
-        float v = 0.f;
-        if (u0 + r < n_batch && f < k) v = P[(int64_t)users[u0 + r] * k + f];
-        pt[r * ld + f] = v;
+    // this lane's user row -> registers (rows beyond the batch and columns beyond k are zero)
+    float preg[KP / 2];
+    {
+        const float *prow = P + (int64_t)(live_u ? users[u0 + col] : 0) * k;
+#pragma unroll
+        for (int j = 0; j < KP / 2; ++j) {
+            const int f = 2 * j + kh;
+            preg[j] = (live_u && f < k) ? prow[f] : 0.f;
+        }
     }
-    // A chunk of Q goes HBM -> registers before the multiply of the previous chunk and registers -> LDS after it,
-    // so the load latency hides behind the MFMA loop (one wave per SIMD: nothing else would hide it).
-    constexpr int KPAD_MAX = TN_WAVES == 4 ? 208 : 256;
-    constexpr int STG = (TN_TILE * KPAD_MAX + TN_WAVES * 64 - 1) / (TN_WAVES * 64);   // floats per thread at the widest row
+    constexpr int STG = CH * KP / 256;     // floats of a chunk per thread (KP is a multiple of 32: exact)
     float stg[STG];
     float stg_b = 0.f;
-    int32_t src_off[STG], dst_off[STG];   // where this thread's elements of a chunk come from and go to (-1: none)
-#pragma unroll
-    for (int t = 0; t < STG; ++t) {
-        const int e = tid + t * TN_WAVES * 64;
-        const int r = e / kpad, f = e - r * kpad;
-        const bool in = e < TN_TILE * kpad;
-        dst_off[t] = in ? r * ld + f : -1;
-        src_off[t] = in && f < k ? r * k + f : -1;
-    }
     auto fetch = [&](int64_t c) {
-        const int64_t i0 = c * TN_TILE;
+        const int64_t i0 = c * CH;
         const float *src = Q + i0 * k;
-        const int32_t lim = (int32_t)std::min<int64_t>(TN_TILE, n_items - i0) * k;   // rows beyond the last item read as 0
+        const int32_t rows = (int32_t)std::min<int64_t>(CH, n_items - i0);   // rows beyond the last item read as 0
 #pragma unroll
-        for (int t = 0; t < STG; ++t) stg[t] = (src_off[t] >= 0 && src_off[t] < lim) ? src[src_off[t]] : 0.f;
-        if (tid < TN_TILE) stg_b = (with_bias && i0 + tid < n_items) ? b_i[i0 + tid] : 0.f;
+        for (int t = 0; t < STG; ++t) {
+            const int e = tid + t * 256;
+            const int r = e / KP, f = e - r * KP;
+            stg[t] = (r < rows && f < k) ? src[r * k + f] : 0.f;
+        }
+        if (tid < CH) stg_b = (with_bias && i0 + tid < n_items) ? b_i[i0 + tid] : 0.f;
     };
     auto commit = [&](int buf) {
-        float *dst = qc + (size_t)buf * TN_TILE * ld;
+        float *dst = qc + (size_t)buf * CH * LD;
 #pragma unroll
-        for (int t = 0; t < STG; ++t)
-            if (dst_off[t] >= 0) dst[dst_off[t]] = stg[t];
-        if (tid < TN_TILE) bc[buf * TN_TILE + tid] = stg_b;
+        for (int t = 0; t < STG; ++t) {
+            const int e = tid + t * 256;
+            const int r = e / KP, f = e - r * KP;
+            dst[r * LD + f] = stg[t];
+        }
+        if (tid < CH) bc[buf * CH + tid] = stg_b;
     };
     float sc[N];
     int32_t id[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) { sc[j] = -INFINITY; id[j] = 0x7fffffff; }
-    const int64_t n_chunks = (n_items + TN_TILE - 1) / TN_TILE;
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    const int col = lane & 31, kh = lane >> 5;          // MFMA operand coordinates of this lane
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int buf = (int)(c & 1);
-        if (c + 1 < n_chunks) fetch(c + 1);             // in flight during the multiply
-        const float *qa = qc + (size_t)buf * TN_TILE * ld + col * ld + kh;   // A[item = col][kk + kh]
-        const float *pb = pt + col * ld + kh;                               // B[kk + kh][user = col]
-        f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // kpad is a multiple of 8 (zero columns beyond k); the operands of the next four MFMAs are read from LDS
-        // while the current four run (one wave per SIMD: nothing else hides the LDS latency)
-        float a0 = qa[0], a1 = qa[2], a2 = qa[4], a3 = qa[6];
-        float p0 = pb[0], p1 = pb[2], p2 = pb[4], p3 = pb[6];
-        for (int kk = 8; kk < kpad; kk += 8) {
-            const float n0 = qa[kk], n1 = qa[kk + 2], n2 = qa[kk + 4], n3 = qa[kk + 6];
-            const float m0 = pb[kk], m1 = pb[kk + 2], m2 = pb[kk + 4], m3 = pb[kk + 6];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, p2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, p3, acc, 0, 0, 0);
-            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-            p0 = m0; p1 = m1; p2 = m2; p3 = m3;
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, p0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, p1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, p2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, p3, acc, 0, 0, 0);
-        if (c + 1 < n_chunks) commit(buf ^ 1);          // the other buffer: nobody reads it before the barrier below
-        // lane holds S^T[item row][user = col] for rows 8*(j/4) + 4*kh + (j%4), j = 0..15
-        const int64_t i0 = c * TN_TILE;
+    // lane holds S^T[item row][user = col] of a tile for rows 8*(j/4) + 4*kh + (j%4), j = 0..15
+    auto select = [&](const f16v &acc, int64_t i0, const float *bias) {
         // A user's two lanes each keep the best N of their own half of the items; the user's N-th best over
         // both halves is at least the larger of the two lanes' N-th bests, so that is the bar a candidate has
         // to pass (strictly: equal scores are settled by the list itself).
@@ -138,7 +114,7 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
         for (int j = 0; j < 16; ++j) {
             const int row = 8 * (j / 4) + 4 * kh + (j % 4);
             const int64_t item = i0 + row;
-            const float s = acc[j] + bc[buf * TN_TILE + row];
+            const float s = acc[j] + bias[row];
             const bool cand = item < n_items && s >= bar &&
                               (s > sc[N - 1] || (s == sc[N - 1] && (int32_t)item < id[N - 1]));
 #ifdef TN_NOSELECT   // timing experiment: multiply only (one value is kept so the MFMAs are not dead code)
@@ -147,11 +123,31 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
             if (__ballot(cand)) insert_top<N>(sc, id, cand ? s : -INFINITY, cand ? (int32_t)item : 0x7fffffff);
 #endif
         }
+    };
+    const int64_t n_steps = (n_items + CH - 1) / CH;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int64_t c = 0; c < n_steps; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < n_steps) fetch(c + 1);              // in flight during the multiply
+        const float *qa0 = qc + (size_t)buf * CH * LD + col * LD + kh;   // A[item = col][2 j + kh] of the first tile
+        const float *qa1 = qa0 + TN_TILE * LD;                           // ... of the second
+        f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f16v acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < KP / 2; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[2 * j], preg[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[2 * j], preg[j], acc1, 0, 0, 0);
+        }
+        if (c + 1 < n_steps) commit(buf ^ 1);           // the other buffer: nobody reads it before the barrier below
+        select(acc0, c * CH, bc + buf * CH);
+        select(acc1, c * CH + TN_TILE, bc + buf * CH + TN_TILE);
         __syncthreads();
     }
-    // merge the two lanes of a user (lane, lane+32) through LDS (the user tile is no longer needed), lane < 32 writes
-    float *ms = pt;                       // [32][N] scores of the upper lanes
-    int32_t *mi = (int32_t *)(pt + TN_TILE * N);
+    // merge the two lanes of a user (lane, lane+32) through LDS (the item chunks are no longer needed), lane < 32 writes
+    float *ms = lds + (size_t)wave * (2 * TN_TILE * N);     // [32][N] scores of the upper lanes, then [32][N] ids
+    int32_t *mi = (int32_t *)(ms + TN_TILE * N);
     if (kh == 1) {
 #pragma unroll
         for (int j = 0; j < N; ++j) { ms[col * N + j] = sc[j]; mi[col * N + j] = id[j]; }
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (kh == 0 && u0 + col < n_batch) {
+    if (kh == 0 && live_u) {
 #pragma unroll
         for (int j = 0; j < N; ++j) insert_top<N>(sc, id, ms[col * N + j], mi[col * N + j]);
         const float add = with_bias ? b_u[users[u0 + col]] + b : 0.f;
@@ -171,22 +167,20 @@ __global__ __launch_bounds__(TN_WAVES * 64) void k_topn(const float *__restrict_
     }
 }
 
-template <int N, int TN_WAVES>
-int launch_topn_w(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const int32_t *users,
-                int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
-                hipStream_t st)
+template <int N, int KP>
+int launch_topn_k(const float *P, const float *Q, const float *b_u, const float *b_i, float b, const int32_t *users,
+                  int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
+                  hipStream_t st)
 {
-    const int kpad = (k + 7) & ~7;
-    const size_t ld = (size_t)kpad + 1;
-    const size_t bytes = ((size_t)(TN_WAVES + 2) * TN_TILE * ld + 2 * TN_TILE) * sizeof(float);
-    MF_ARG(bytes <= (size_t)160 * 1024, "topn: k=%d needs %zu bytes of LDS", k, bytes);
-    MF_ARG((size_t)TN_TILE * ld >= (size_t)2 * TN_TILE * N, "topn: k=%d too small for N=%d", k, N);
-    auto kern = k_topn<N, TN_WAVES>;
+    constexpr size_t bytes = ((size_t)2 * 2 * TN_TILE * (KP + 1) + 2 * 2 * TN_TILE) * sizeof(float);
+    static_assert(bytes <= (size_t)160 * 1024, "item chunks must fit a CU's LDS");
+    static_assert((size_t)2 * 2 * TN_TILE * (KP + 1) >= (size_t)4 * 2 * TN_TILE * N, "the final merge reuses the chunk buffers");
+    auto kern = k_topn<N, KP>;
     MF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    const int64_t per_wg = (int64_t)TN_WAVES * TN_TILE;
+    const int64_t per_wg = (int64_t)4 * TN_TILE;
     const unsigned grid = (unsigned)((n_batch + per_wg - 1) / per_wg);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TN_WAVES * 64), bytes, st, P, Q, b_u, b_i, b, users, n_batch, n_items, k,
-                       kpad, with_bias, out_items, out_scores);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias,
+                       out_items, out_scores);
     MF_LAUNCH_CHECK();
     return MFSGD_OK;
 }
@@ -196,8 +190,13 @@ int launch_topn(const float *P, const float *Q, const float *b_u, const float *b
                 int64_t n_batch, int64_t n_items, int k, int with_bias, int32_t *out_items, float *out_scores,
                 hipStream_t st)
 {
-    if (k <= 200) return launch_topn_w<N, 4>(P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias, out_items, out_scores, st);
-    return launch_topn_w<N, 2>(P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias, out_items, out_scores, st);
+#define MF_TN(KP_) case KP_: return launch_topn_k<N, KP_>(P, Q, b_u, b_i, b, users, n_batch, n_items, k, with_bias, out_items, out_scores, st);
+    switch ((k + 31) & ~31) {
+        MF_TN(32) MF_TN(64) MF_TN(96) MF_TN(128) MF_TN(160) MF_TN(192) MF_TN(224) MF_TN(256)
+    }
+#undef MF_TN
+    mfsgd_set_error("topn: k=%d outside [32,256]", k);
+    return MFSGD_ERR_ARG;
 }
 
 }  // namespace

@@ -96,7 +96,7 @@ def gather_items(plan, rank, Q, b_i, dist):
 # what profiles/dsgd_rank_sim.py measured for ONE rank's sub-epoch kernel on an MI355X (netflix shape, k = 128)
 SUB_EPOCH_BLOCK_US = 15.0       # a block's fixed cost on the stripe's critical path: transition + pipeline fill
 SUB_EPOCH_RATE = 15.0           # ratings per microsecond and workgroup when nothing waits
-CHAIN_LINK_US = (0.12, 0.22)    # one link of an item's chain: hot-item pipeline, item tickets (profiles/r2_chain_link.txt)
+CHAIN_LINK_US = (0.09, 0.22)    # one link of an item's chain: hot-item walker, item tickets (profiles/dev_walker.py, r2_chain_link.txt)
 
 
 def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, max_item_degree=None, n_cus=256):
@@ -117,7 +117,7 @@ def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, max_item_degre
     for cols in range(max(cmin, 8), min(n_cus, max(1, n_items // world)) + 1, 4):
         rows = min(cols + max(1, cols // 8), max(1, n_users // world))
         ibp = -(-n_items // (cols * world))
-        piped = k in (64, 128) and esz == 4 and lds_bytes(ibp, rows, k, 4, 2) <= 160 * 1024
+        piped = k in (64, 128, 256) and esz == 4 and lds_bytes(ibp, rows, k, 4) <= 160 * 1024
         chain = max_item_degree / world * CHAIN_LINK_US[0 if piped else 1]
         t = max(chain + rows * SUB_EPOCH_BLOCK_US, per / (cols * SUB_EPOCH_RATE))
         if best is None or t < best[0] - 1e-9:
@@ -131,12 +131,11 @@ def choose_multi_grid(n_users, n_items, n_train, world, k, esz=4, max_item_degre
 
 
 def pipeline_fits(n_items, ibp, rows, k, hot_buffers=8):
-    """Hot segments in a rank's shard grids: only where the free-block launch will walk them with the hot-item
-    pipeline (SGDRecommender.ExplicitMF._pipeline_runs: fp32, k = 64 / 128, stripe plus two row buffers within
-    a CU's LDS; a shard never has more non-empty stripes than the chooser's 256, so one workgroup runs per CU)."""
+    """Hot segments in a rank's shard grids: only where the free-block launch will walk them with the hot-item walker
+    (SGDRecommender.ExplicitMF._walker_runs: fp32 here, k = 64 / 128 / 256, the stripe within a CU's LDS; a shard never
+    has more non-empty stripes than the chooser's 256, so one workgroup runs per CU)."""
     from .SGDRecommender import lds_bytes
-    return (k in (64, 128) and hot_buffers > 0
-            and lds_bytes(ibp, rows, k, 4, min(2, hot_buffers)) <= 160 * 1024)
+    return k in (64, 128, 256) and hot_buffers > 0 and lds_bytes(ibp, rows, k, 4) <= 160 * 1024
 
 
 class RankWorker:
@@ -253,7 +252,7 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     plan0 = DSGDPlan(U, I, world, ubp, ibp)
     rows = max(1, -(-(plan0.user_range(0)[1] - plan0.user_range(0)[0]) // ubp))
     cost = item_costs(di, rows, plan0.Gc, pipeline_fits(I, ibp, rows, k, args.hot_buffers), 1,
-                      None if args.hot_cost < 0 else args.hot_cost)
+                      None if args.hot_cost < 0 else args.hot_cost, walker=True)
     rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
     cp = torch.from_numpy(interleave_stripes(balanced_permutation(di, ibp, cost), ibp, world).astype(np.int32)).cuda()
     lib = _abi.lib()
