@@ -18,6 +18,12 @@ namespace {
 
 constexpr int TN_TILE = 32;     // users per wave, items per chunk
 constexpr int TN_MAX = 16;      // largest N
+#ifndef TN_SCHED
+#define TN_SCHED 8
+#endif
+#ifndef TN_OCC2_MAX
+#define TN_OCC2_MAX 128   // widest padded k built for two workgroups per CU (256 registers per lane)
+#endif
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -48,7 +54,7 @@ __device__ __forceinline__ void insert_top(float (&sc)[N], int32_t (&id)[N], flo
 //    registers -> LDS after it.  LDS: 2 x 64 x (KP + 1) floats = 66 KB at k = 128 (two workgroups per CU: two waves per
 //    SIMD), 132 KB at k = 256.
 template <int N, int KP>
-__global__ __launch_bounds__(256, KP <= 128 ? 2 : 1) void k_topn(const float *__restrict__ P, const float *__restrict__ Q,
+__global__ __launch_bounds__(256, (KP <= 96 || (KP <= TN_OCC2_MAX && N <= 8)) ? 2 : 1) void k_topn(const float *__restrict__ P, const float *__restrict__ Q,
                                                                 const float *__restrict__ b_u, const float *__restrict__ b_i,
                                                                 float b, const int32_t *__restrict__ users, int64_t n_batch,
                                                                 int64_t n_items, int k, int with_bias,
@@ -66,11 +72,14 @@ __global__ __launch_bounds__(256, KP <= 128 ? 2 : 1) void k_topn(const float *__
     // this lane's user row -> registers (rows beyond the batch and columns beyond k are zero)
     float preg[KP / 2];
     {
-        const float *prow = P + (int64_t)(live_u ? users[u0 + col] : 0) * k;
+        // every load is unconditional (a clamped address, the value masked afterwards): a conditional load becomes a
+        // branch, and 64 of them with their exec masks cost more registers than the rows themselves
+        const float *prow = P + (int64_t)users[live_u ? u0 + col : 0] * k;
 #pragma unroll
         for (int j = 0; j < KP / 2; ++j) {
             const int f = 2 * j + kh;
-            preg[j] = (live_u && f < k) ? prow[f] : 0.f;
+            const float v = prow[f < k ? f : 0];
+            preg[j] = (live_u && f < k) ? v : 0.f;
         }
     }
     constexpr int STG = CH * KP / 256;     // floats of a chunk per thread (KP is a multiple of 32: exact)
@@ -84,7 +93,9 @@ __global__ __launch_bounds__(256, KP <= 128 ? 2 : 1) void k_topn(const float *__
         for (int t = 0; t < STG; ++t) {
             const int e = tid + t * 256;
             const int r = e / KP, f = e - r * KP;
-            stg[t] = (r < rows && f < k) ? src[r * k + f] : 0.f;
+            const bool in = r < rows && f < k;
+            const float v = src[in ? r * k + f : 0];          // unconditional, see above (i0 < n_items: src[0] exists)
+            stg[t] = in ? v : 0.f;
         }
         if (tid < CH) stg_b = (with_bias && i0 + tid < n_items) ? b_i[i0 + tid] : 0.f;
     };
@@ -139,6 +150,9 @@ __global__ __launch_bounds__(256, KP <= 128 ? 2 : 1) void k_topn(const float *__
         for (int j = 0; j < KP / 2; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[2 * j], preg[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[2 * j], preg[j], acc1, 0, 0, 0);
+            // the loop is fully unrolled (preg is a register array); keep the scheduler from hoisting all KP item
+            // operand reads in front of it: at k = 128 that spilled 45 registers of the 256 two workgroups per CU leave
+            if (j % TN_SCHED == TN_SCHED - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < n_steps) commit(buf ^ 1);           // the other buffer: nobody reads it before the barrier below
         select(acc0, c * CH, bc + buf * CH);
