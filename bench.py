@@ -99,6 +99,7 @@ def run_leg(args, torch, ra, data, k, hot_buffers, renumber=None):
                       grid=tuple(int(x) for x in args.grid.split(",")) if args.grid else None,
                       n_workgroups=args.wgs, waves_per_wg=args.waves, hot_buffers=hot_buffers, hot_mode=args.hot_mode,
                       **({} if args.hot_items < 0 else {"hot_items": args.hot_items}),
+                      **({} if not args.user_order else {"user_order": args.user_order}),
                       **({} if args.hot_cost < 0 else {"hot_cost": args.hot_cost}),
                       **({} if args.hot_min < 0 else {"hot_min": args.hot_min}), verbose=False)
     m.load_samples_from_device(train.clone(), test.clone(), U, I)      # renumbering rewrites the ids in place
@@ -158,6 +159,8 @@ def main():
                     help="hot items (hot segments per block) a stripe may have where the pipeline runs (default: the library's)")
     ap.add_argument("--hot-min", type=int, default=-1,
                     help="ratings per block an item needs to become a hot item (default: the model's, 64)")
+    ap.add_argument("--user-order", default="", choices=["", "heavy", "light", "shuffle", "spread"],
+                    help="order of a user stripe's ids under the balanced renumbering (= order of a block's runs)")
     ap.add_argument("--hot-mode", type=int, default=2,
                     help="hot segments: 2 = hot-item walker (default), 1 = matrix-core pipeline, 0 = item tickets")
     ap.add_argument("--hot-buffers", type=int, default=8,

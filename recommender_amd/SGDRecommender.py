@@ -92,6 +92,35 @@ def _balanced_by_cost(deg, cost, width):
     return new_id
 
 
+def reorder_within_stripes(new_id, width, mode, seed=0):
+    """The deal numbers a stripe's ids in the order it hands them out: most rated first.  Inside a block the runs are
+    stored by user id, so that is also the order in which a block's runs are walked.  mode "heavy" keeps it, "light"
+    reverses it inside every stripe, "shuffle" permutes every stripe's ids at random (seeded), "spread" interleaves the
+    stripe's heavy half with its light half.  The stripes' contents - and their balance - do not change."""
+    if mode == "heavy":
+        return new_id
+    new_id = np.asarray(new_id)
+    N = len(new_id)
+    stripe, slot = new_id // width, new_id % width
+    size = np.bincount(stripe, minlength=int(stripe.max()) + 1)[stripe]           # ids in this id's stripe
+    if mode == "light":
+        slot2 = size - 1 - slot
+    elif mode == "spread":      # slot s of the heavy half -> 2 s, slot s of the light half -> 2 (s - half) + 1
+        half = (size + 1) // 2
+        slot2 = np.where(slot < half, 2 * slot, 2 * (slot - half) + 1)
+    elif mode == "shuffle":
+        rng = np.random.default_rng(seed)
+        key = stripe.astype(np.float64) + rng.random(N)                            # random order inside every stripe
+        order = np.argsort(key, kind="stable")
+        first = np.zeros(int(stripe.max()) + 2, dtype=np.int64)
+        np.cumsum(np.bincount(stripe, minlength=int(stripe.max()) + 1), out=first[1:])
+        slot2 = np.empty(N, dtype=np.int64)
+        slot2[order] = np.arange(N) - first[stripe[order]]
+    else:
+        raise ValueError(f"reorder_within_stripes: unknown mode {mode!r}")
+    return stripe * width + slot2
+
+
 CHAIN_RATING_COST = 5.0     # a rating of a stripe's most rated item on the ticket path against any other rating there
 HOT_RATING_COST = 0.8       # a rating on the matrix-core pipeline against one on the ticket path, as the dealing should count
                             # it (netflix shape, k = 128, swept 0.25 .. 1.0: 25.4 ms per epoch at 0.25, 24.1 at 0.7 - 0.85,
@@ -265,6 +294,7 @@ class ExplicitMF(Recommender):
                  hot_mode=2,             # hot segments: 2 = register-resident walker (one hot item per stripe), 1 = matrix-core pipeline, 0 = tickets
                  hot_cost=None,          # cost of a pipeline rating against a ticket-path one in balanced_renumber_samples
                  hot_min=64,             # ratings per block (on average) an item needs to become a hot item (two pipeline batches)
+                 user_order="heavy",     # balanced renumbering: order of a stripe's users (= of a block's runs), reorder_within_stripes
                  pad_factors=True,       # throughput mode: device copies of P / Q / y get zero columns up to a multiple of 64
                  pass_barrier=False,     # False: the passes of one run_epochs call overlap like the reference's scheduler lets
                                          # them (schedule 2: one launch, least-visited-of-two); True: a launch per pass
@@ -288,6 +318,7 @@ class ExplicitMF(Recommender):
         self.hot_mode = int(hot_mode)
         self.hot_cost = hot_cost
         self.hot_min = int(hot_min)
+        self.user_order = user_order
         self.pad_factors = bool(pad_factors)
         self.pass_barrier = bool(pass_barrier)
         self.pick_width = pick_width
@@ -450,7 +481,7 @@ class ExplicitMF(Recommender):
                 Gc = min(I, 512)
                 ibp0 = -(-I // max(Gc, Gc_min))
                 two = esz == 4 and k <= 128 and lds_bytes(ibp0, 640, k, esz) <= 80 * 1024
-                Gr = min(U, 640 if two else 320)      # Yahoo shape, k=256: 640 -> 320 rows took 276 -> 201 ms
+                Gr = min(U, 640 if two else 272)      # Yahoo shape, k=256: 640 -> 320 rows took 276 -> 201 ms; round 3: 320 rows 186.5, 288 181.6, 272 179.6
                 want = max(1.0, n / 200.0)
                 if Gr * Gc > want:
                     f = (want / (Gr * Gc)) ** 0.5
@@ -659,7 +690,8 @@ class ExplicitMF(Recommender):
         Gr, Gc = -(-self.n_users // ubp), -(-self.n_items // ibp)
         cost = item_costs(di, Gr, Gc, self._hot_path_runs(Gr, Gc), self.hot_items, self.hot_cost, self.hot_min,
                           walker=self._walker_runs(Gr, Gc))
-        self._apply_renumbering(balanced_permutation(du, ubp), balanced_permutation(di, ibp, cost))
+        self._apply_renumbering(reorder_within_stripes(balanced_permutation(du, ubp), ubp, self.user_order, self.seed),
+                                balanced_permutation(di, ibp, cost))
 
     def _apply_renumbering(self, row_index, col_index):
         """Remap ids by `row_index` / `col_index` (current id -> new id).  self.row_perm / col_perm always map the
