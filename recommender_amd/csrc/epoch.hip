@@ -133,6 +133,25 @@ constexpr int MAX_PASSES_PER_LAUNCH = 200;   // visit counts live in one byte pe
     } while (0)
 #endif
 
+// How a user stripe's rows pass from one workgroup to the next (row lock, k_epoch_free).
+//  * The general build (FAST == 0: plain loads and stores of P / b_u) brackets the lock with agent-scope fences: release =
+//    write back this XCD's L2 (buffer_wbl2), acquire = invalidate the CU's L1 and the L2's non-local lines (buffer_inv) -
+//    the XCDs of an MI355X have an L2 each.  That is bulk cache maintenance on every block transition: 5-6 us per block
+//    (netflix shape 21.2 -> 19.5 ms per epoch, ML-25M 8.9 -> 7.5 without it - timing experiment, stale rows, -DMFSGD_NOFENCE).
+//  * The straight-line builds (FAST != 0) need no fence: every access to P and b_u there is itself coherent at agent
+//    scope - loads as relaxed agent-scope atomic loads (row_get_agent: global_load ... sc1), stores with the sc1 bit
+//    (untracked_store, row_put_untracked, the walker's vm_* helpers) - so a row is read from and written through to the
+//    memory side of the L2s, never left in a cache another XCD cannot see.  What remains of release / acquire is ordering:
+//    the holder's stores have completed (s_waitcnt vmcnt(0) before the closing barrier) before the lock word is cleared,
+//    and the next holder's loads are issued after its compare-and-swap has returned.  P rows have no reuse inside a block
+//    (a run loads its row once and stores it once), so nothing is lost by not caching them.
+#ifdef MFSGD_NOFENCE   // timing experiment for the general build: no cache maintenance at the row hand-off (stale rows)
+#define MF_AGENT_RELEASE() asm volatile("" ::: "memory")
+#define MF_AGENT_ACQUIRE() asm volatile("" ::: "memory")
+#else
+#define MF_AGENT_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define MF_AGENT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // ------------------------------------------------------------------------------------------ grid build
@@ -476,11 +495,11 @@ LdsPlan<T> lds_plan(int32_t ibp, int32_t Gr, int32_t k, bool stage, bool dynamic
 
 __device__ __forceinline__ void untracked_store(float *p, float v)
 {
-    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void untracked_store(double *p, double v)
 {
-    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Lane -> factor map of the walk (load_run / walk_run): lane l holds the KC CONSECUTIVE factors KC*l .. KC*l + KC-1 of a
@@ -513,6 +532,27 @@ __device__ __forceinline__ void row_put(T *row, int lane, const T (&x)[KC])
         for (int c = 0; c < KC; ++c) row[KC * lane + c] = x[c];
     }
 }
+// A row of P from device memory, coherent at agent scope (see MF_AGENT_RELEASE): relaxed agent-scope atomic loads of 4 or 8
+// bytes (global_load_dword / dwordx2 ... sc1), which the compiler tracks like any other load (exact vmcnt waits).
+template <typename T, int KC>
+__device__ __forceinline__ void row_get_agent(const T *row, int lane, T (&x)[KC])
+{
+    constexpr int BYTES = KC * (int)sizeof(T);
+    const T *p = row + KC * lane;
+    if constexpr (BYTES % 8 == 0) {
+        union { uint64_t w[BYTES / 8]; T v[KC]; } u;
+#pragma unroll
+        for (int i = 0; i < BYTES / 8; ++i)
+            u.w[i] = __hip_atomic_load((const uint64_t *)p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) x[c] = u.v[c];
+    } else {
+        static_assert(sizeof(T) == 4, "rows of 4-byte elements");
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            x[c] = __uint_as_float(__hip_atomic_load((const uint32_t *)p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
 // the same store outside the compiler's vmcnt bookkeeping (see walk_run's tail)
 template <int KC>
 __device__ __forceinline__ void row_put_untracked(float *row, int lane, const float (&x)[KC])
@@ -521,16 +561,16 @@ __device__ __forceinline__ void row_put_untracked(float *row, int lane, const fl
     if constexpr (KC == 2) {
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 v = {x[0], x[1]};
-        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     } else if constexpr (KC == 4) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 v = {x[0], x[1], x[2], x[3]};
         // a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers (two wait
         // states on gfx90a-class targets); hipcc's hazard recognizer cannot see into the asm statement
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     } else {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) asm volatile("global_store_dword %0, %1, off" ::"v"(p + c), "v"(x[c]) : "memory");
+        for (int c = 0; c < KC; ++c) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p + c), "v"(x[c]) : "memory");
     }
 }
 template <int KC>
@@ -542,10 +582,10 @@ __device__ __forceinline__ void row_put_untracked(double *row, int lane, const d
         const d2 v = {x[0], x[1]};
         // a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers (two wait
         // states on gfx90a-class targets); hipcc's hazard recognizer cannot see into the asm statement
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     } else {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p + c), "v"(x[c]) : "memory");
+        for (int c = 0; c < KC; ++c) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p + c), "v"(x[c]) : "memory");
     }
 }
 
@@ -599,7 +639,7 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     h.t1 = __builtin_amdgcn_readfirstlane(x.t1);
     const T *prow = P + (int64_t)h.u * k;
     if constexpr (FAST != 0) {
-        row_get<T, KC>(prow, lane, h.p);
+        row_get_agent<T, KC>(prow, lane, h.p);
         if constexpr (FAST == 2) {
             row_get<T, KC>(z + (int64_t)h.u * k, lane, h.zz);
         } else {
@@ -618,7 +658,7 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
         }
     }
     // biases are rewritten by other workgroups earlier in this launch: atomic loads never become scalar loads
-    h.bu = __hip_atomic_load(&b_u[h.u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    h.bu = __hip_atomic_load(&b_u[h.u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     load_meta(g, h.t0, h.t1, lane, h.m_item, h.m_tick, h.m_val);
 }
 
@@ -950,7 +990,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
             }
             LDS_ACQUIRE();
         }
-        const float buj = __hip_atomic_load(&b_u[uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const float buj = __hip_atomic_load(&b_u[uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float rest = hv[base + ej] - b - buj;
         PF_T(a0);
         // 1. the users' rows -> LDS, natural layout, with coalesced 128-bit loads (RPI whole rows per instruction)
@@ -960,8 +1000,12 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
             for (int t = 0; t < PA_B / RPI; ++t) {
                 const int row = t * RPI + rsub;
                 const int32_t ur = __builtin_amdgcn_ds_bpermute(4 * row, uj);   // lane `row` holds entry `row`
-                const pa_f32x4 v = *(const pa_f32x4 *)(P + (int64_t)ur * K + cpos);
-                *(pa_f32x4 *)(buf + row * LD + cpos) = v;
+                // (agent-scope loads, see MF_AGENT_RELEASE: two 8-byte halves)
+                const uint64_t *src = (const uint64_t *)(P + (int64_t)ur * K + cpos);
+                union { uint64_t w[2]; pa_f32x4 v; } u;
+                u.w[0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u.w[1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(pa_f32x4 *)(buf + row * LD + cpos) = u.v;
             }
         }
         PF_PIN(buf[lane]);
@@ -1170,12 +1214,27 @@ __device__ __forceinline__ void vm_load_so(V &dst, const void *sbase, uint32_t v
     else if constexpr (sizeof(V) == 8) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
+// ... and the forms for P and b_u, coherent at agent scope (sc1; see MF_AGENT_RELEASE)
+template <typename V>
+__device__ __forceinline__ void vm_load_agent(V &dst, const void *addr)
+{
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8, "vm_load_agent: 4 or 8 bytes per lane");
+    if constexpr (sizeof(V) == 4) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(dst) : "v"(addr) : "memory");
+    else asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(dst) : "v"(addr) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void vm_load_so_agent(V &dst, const void *sbase, uint32_t voff)
+{
+    if constexpr (sizeof(V) == 4) asm volatile("global_load_dword %0, %1, %2 sc1" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
 template <typename V>
 __device__ __forceinline__ void vm_store_so(const V &src, void *sbase, uint32_t voff)
 {
-    if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
-    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");   // > 64 bits: hazard nop
+    if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");   // > 64 bits: hazard nop
 }
 __device__ __forceinline__ float fma_t(float x, float y, float w) { return __builtin_fmaf(x, y, w); }
 __device__ __forceinline__ double fma_t(double x, double y, double w) { return __builtin_fma(x, y, w); }
@@ -1260,15 +1319,15 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
     ids(128, ujC, vC);
     vm_wait<0>(ujA);
     asm volatile("" : "+v"(ujB), "+v"(vA), "+v"(vB), "+v"(ujC), "+v"(vC));   // all six have arrived
-    vm_load(buA, b_u + ujA);
-    vm_load(buB, b_u + ujB);
+    vm_load_agent(buA, b_u + ujA);
+    vm_load_agent(buB, b_u + ujB);
     Row rp[D], rz[HASZ ? D : 1];
 #pragma unroll
     for (int s = 0; s < D; ++s) {
         rp[s] = Row{};
         if constexpr (HASZ) rz[s] = Row{};
         const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane(ujA, s) * row_bytes + lane_off;
-        vm_load_so(rp[s], P, ro);
+        vm_load_so_agent(rp[s], P, ro);
         if constexpr (HASZ) vm_load_so(rz[s], z, ro);
     }
     // per-lane byte offset of every link's row: one readlane + one v_add per request in the loop
@@ -1356,7 +1415,7 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
             // the slot is free: request the row of the link HOT_RING further on
             const uint32_t ro = (uint32_t)(li + DD < 64 ? __builtin_amdgcn_readlane(offA, (li + DD) & 63)
                                                         : __builtin_amdgcn_readlane(offB, (li + DD) & 63)) + lane_off;
-            vm_load_so(rp[s], P, ro);
+            vm_load_so_agent(rp[s], P, ro);
             if constexpr (HASZ) vm_load_so(rz[s], z, ro);
         }
         if constexpr (ROLE == 0) {
@@ -1386,7 +1445,7 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
         ujB = ujC; vB = vC;
         offA = offB; offB = (uint32_t)ujB * row_bytes;
         asm volatile("" : "+v"(ujA), "+v"(vA), "+v"(buA), "+v"(ujB), "+v"(vB), "+v"(offA), "+v"(offB));   // the copies happen HERE, before the reloads
-        vm_load(buB, b_u + ujB);
+        vm_load_agent(buB, b_u + ujB);
         ids(base + 192, ujC, vC);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests land before their registers are reused
@@ -1769,7 +1828,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                 auto release = [&]() {
                     // every wave drained its stores before the barrier that ended process_block
                     if (held >= 0) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        if constexpr (FAST == 0) MF_AGENT_RELEASE();
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         held = -1;
@@ -1840,7 +1899,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
                     row_done[found] = (unsigned char)(row_done[found] + 1);   // every lane, same value
                     ctl[CTL_REMAIN] = remain - 1;
                     // acquire: drop this CU's L1 so that the previous holder's P rows are re-read
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if constexpr (FAST == 0) MF_AGENT_ACQUIRE();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (s.order_log) {
                         const int32_t slot = __builtin_amdgcn_readlane(
@@ -1857,7 +1916,7 @@ __global__ __launch_bounds__(1024, WPS) void k_epoch_free(GridView g, T *P, T *Q
             if (sched_wave) {
                 // the finished block's row goes back while the other waves already start on the next block
                 if (held >= 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if constexpr (FAST == 0) MF_AGENT_RELEASE();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&s.row_lock[held], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -301,7 +301,7 @@ def _synthetic(rng, U, I, n, lead=False):
 
 
 def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1, dt=np.float32, tol=1e-4, variant=0,
-                 lead=None, iters=2, hot=None, pick=None):
+                 lead=None, iters=2, hot=None, pick=None, hot_mode=None):
     """Run `iters` epochs on the GPU with the block order logged, replay that order block by block through the CPU
     oracle's plain sequential kernel (orc_sgd) in the grid's stored order, compare the factors."""
     import torch
@@ -319,6 +319,8 @@ def _replay_case(ra, orc, k, U, I, n, grid, waves, mode, hot_bufs=8, schedule=1,
     gr.set_hot_buffers(hot_bufs)
     if pick is not None:
         gr.set_pick_width(pick)
+    if hot_mode is not None:
+        gr.set_hot_mode(hot_mode)
     col_hot = gr.col_hot()
     assert gr.info.n_hot_stripes == (col_hot[:, 0] >= 0).sum() and gr.info.n_hot_items == (col_hot >= 0).sum()
     assert all(h < 0 or h // ibp == c for c, row in enumerate(col_hot) for h in row)
@@ -400,45 +402,51 @@ def test_overlapped_passes_replay_on_oracle(ra, orc):
     assert seen_overlap
 
 
-@pytest.mark.parametrize("hot_bufs", [0, 2, 8])
-def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_bufs):
+@pytest.mark.parametrize("hot_bufs,hot_mode", [(0, 2), (2, 2), (8, 2), (8, 1), (2, 1)])
+def test_hot_item_pipeline_replays_on_the_plain_sequential_oracle(ra, orc, hot_bufs, hot_mode):
     """Blocks whose stripe has a hot item store that item's ratings as a segment in front.  hot_bufs = 0 walks the
-    segment through the item's tickets like any other rating; hot_bufs > 0 sends it through the hot-item pipeline
-    (phase_a_gram: Gram tile on the matrix cores + scalar chain), which restates the same sequential updates.  Both
+    segment through the item's tickets like any other rating; hot_bufs > 0 sends it through a hot-item path: with
+    hot_mode 2 (the default) the register-resident walker (hot_walk: the sequential arithmetic itself, on two waves) for
+    stripes with one hot item and the matrix-core pipeline for stripes with several, with hot_mode 1 the pipeline
+    everywhere (phase_a_gram: Gram tile on the matrix cores + scalar chain, a restatement of the same updates).  All
     must agree with the oracle's plain sequential kernel replaying the stored order - there is no relaxed mode.
     k = 128, 64 and 256, both update orders (sgd / sgd2), segments longer than one batch, longer than the LDS table
     (1024), shorter than a batch, and fewer waves than buffers."""
-    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs)
+    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode)
     assert info.n_hot > 1000 and info.n_hot_stripes >= 1
-    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs)
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, variant=1)
-    info = _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, lead=True)   # ~1500 per segment
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs, hot_mode=hot_mode)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, variant=1)
+    info = _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True)   # ~1500 per segment
     assert info.n_hot > 2500
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 2, "none", hot_bufs=hot_bufs)               # fewer waves than buffers
-    info = _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, lead=True)   # k = 256: 64 lanes per row
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 2, "none", hot_bufs=hot_bufs, hot_mode=hot_mode)               # fewer waves than buffers
+    info = _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True)   # k = 256: 64 lanes per row
     assert info.n_hot > 1000
     # several hot items per stripe (mfsgd_grid_create_opt): a user may sit in several segments and in the rest
-    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 16, "none", hot_bufs=hot_bufs, hot=(8, 1))
+    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 16, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, hot=(8, 1))
     assert info.n_hot_items > info.n_hot_stripes >= 1 and info.n_hot > 5000
-    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs, hot=(4, 2), variant=1)
-    _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, lead=True, hot=(8, 1))   # segments longer than the LDS table
-    _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, lead=True, hot=(3, 8))
+    _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, hot=(4, 2), variant=1)
+    _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True, hot=(8, 1))   # segments longer than the LDS table
+    _replay_case(ra, orc, 256, 3000, 600, 150000, (32, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True, hot=(3, 8))
     # the other kernels (k not 64, 128 or 256, implicit term, the fixed schedule) take the ticket path whatever hot_bufs says
-    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, lead=True)
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs)
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, schedule=0)
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs, hot=(8, 1))
-    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, lead=True, hot=(8, 1))
-    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, schedule=0, hot=(8, 1))
+    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs, hot_mode=hot_mode)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, schedule=0)
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "frozen", hot_bufs=hot_bufs, hot_mode=hot_mode, hot=(8, 1))
+    _replay_case(ra, orc, 200, 700, 400, 40000, (4, 8), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, lead=True, hot=(8, 1))
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", hot_bufs=hot_bufs, hot_mode=hot_mode, schedule=0, hot=(8, 1))
 
 
 def test_free_block_and_hot_segments_in_float64(ra, orc):
     """The fp64 epoch kernels against the fp64 oracle: the logged order replays to 1e-9 (summation trees differ);
-    hot segments included (fp64 always takes the ticket path)."""
+    hot segments included (one hot item per stripe: the walker, which runs in fp64 too; several: the ticket path)."""
     _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", dt=np.float64, tol=1e-9)
     _replay_case(ra, orc, 40, 700, 400, 40000, (16, 8), 8, "frozen", dt=np.float64, tol=1e-9)
     _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", schedule=0, dt=np.float64, tol=1e-9)
     _replay_case(ra, orc, 64, 2000, 5000, 150000, (32, 32), 16, "none", dt=np.float64, tol=1e-9, hot=(8, 1))
+    info = _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", dt=np.float64, tol=1e-9, lead=True)   # walker, fp64
+    assert info.n_hot > 1000
+    _replay_case(ra, orc, 64, 6000, 600, 250000, (2, 8), 16, "frozen", dt=np.float64, tol=1e-9, lead=True)          # walker with z, long segments
+    _replay_case(ra, orc, 128, 3000, 900, 200000, (64, 16), 8, "none", dt=np.float64, tol=1e-9, lead=True, hot_mode=0)
 
 
 def test_hot_segment_arguments_and_duplicates(ra):
