@@ -168,16 +168,17 @@ int mfsgd_grid_create(const int32_t *samples, int64_t n, int32_t stride, int64_t
  * items become its hot items - item s's ratings form hot segment s in front of every block of the stripe, one
  * single-rating run per user, by user - each with at least 256 ratings and, on average, at least hot_min_per_block
  * ratings per block of the stripe (degree >= hot_min_per_block * Gr); hot_items = 0: no hot segments at all (every
- * block of an order-1 grid sorted by user only).  A rating that goes through the hot-item pipeline
- * (mfsgd_grid_set_hot_buffers) costs about half of one that goes through the item tickets (0.12 against 0.22 us per link of one item's chain, k = 128),
- * in batches of 32; hot segments that go through the tickets cost time (a block then starts with a stretch in
- * which every wave waits for the same item).  So a caller that knows the pipeline will run passes (1, 64) - ExplicitMF.build_grid does -
- * and one that knows it will not - k other than 64 / 128 / 256, fp64, an implicit term, item stripes that leave no
- * LDS for its row buffers - passes (0, 0).  mfsgd_grid_create is one hot item per stripe of any length, if it
- * carries >= 1/16 of the stripe's ratings - a default for callers that will run fp32, k = 64 / 128 / 256 without an
- * implicit term on stripes that leave LDS for at least two row buffers (the launch then walks the segments with the
- * pipeline and runs one workgroup per CU); every other caller should say (0, 0) here: its hot segments would go
- * through the tickets, which is slower than no hot segments (ML-25M shape: 13.0 against 11.8 ms per epoch). */
+ * block of an order-1 grid sorted by user only).  A rating on a hot path (mfsgd_grid_set_hot_mode: the hot-item walker,
+ * 0.09 us per link of the item's chain at k = 128; the matrix-core pipeline, 0.12) costs less than half of one that goes
+ * through the item tickets (0.22 us per link); hot segments that go through the tickets cost time (a block then starts
+ * with a stretch in which every wave waits for the same item).  So a caller that knows a hot path will run passes
+ * (1, 64) - ExplicitMF.build_grid does - and one that knows it will not passes (0, 0).  The walker runs in every
+ * straight-line build: k = 64, 128 or 256 (pad the device rows with zero columns otherwise), fp32 or fp64, with or
+ * without the frozen implicit term, a user-unique grid (order 1 always is) whose item stripes fit a CU's LDS
+ * (mfsgd_lds_bytes), sgd's update order (variant 0), one hot item per stripe.  mfsgd_grid_create is one hot item per
+ * stripe of any length, if it carries >= 1/16 of the stripe's ratings - the default for those callers; every other
+ * caller should say (0, 0) here: its hot segments would go through the tickets, which is slower than no hot segments
+ * (ML-25M shape: 13.0 against 11.8 ms per epoch). */
 int mfsgd_grid_create_opt(const int32_t *samples, int64_t n, int32_t stride, int64_t n_users, int64_t n_items,
                           int32_t ubp, int32_t ibp, int32_t order, int32_t hot_items, int32_t hot_min_per_block,
                           void *stream, mfsgd_grid **out);
@@ -192,21 +193,24 @@ int mfsgd_grid_export(const mfsgd_grid *g, int32_t *blk_run_ptr, int32_t *run_st
  * memory system, bounds their stripes.  A stripe's most rated item becomes its HOT item when it carries >= 1/16 of
  * the stripe's ratings (and >= 256); every block of the stripe then stores that item's ratings first, one single-
  * rating run per user, in user order.  Nothing is relaxed: the block is still walked sequentially in stored order,
- * and the free-block kernel (fp32, k = 64, 128 or 256, no implicit term) walks a hot segment with the hot-item pipeline - the same
- * chain of updates, restated so that the serial part of a link is a few scalar operations (Gram tile of the users'
- * rows on the matrix cores, csrc/epoch.hip phase_a_gram); every other kernel walks it through the item tickets.
+ * and the free-block kernel walks a hot segment on a hot path (mfsgd_grid_set_hot_mode below) - the same chain of
+ * updates on two waves of its own, or restated so that the serial part of a link is a few scalar operations; every
+ * other kernel walks it through the item tickets.
  * The reference has no counterpart (its blocks are walked by one thread, RayBlockScheduler.py:127-143).
- * mfsgd_grid_set_hot_buffers: how many LDS row buffers (0..8, default 8 = as many as fit; each 32 x (k+4) floats, one per pipeline wave) the pipeline may
- * take behind the stripe; 0 sends hot segments through the tickets too (same results up to rounding - the tests
- * replay both on the oracle's plain sequential kernel).  Takes effect from the next epoch call. */
+ * mfsgd_grid_set_hot_buffers: how many LDS row buffers (0..8, default 8 = as many as fit; each 32 x (k+4) floats, one per
+ * pipeline wave) the matrix-core pipeline may take behind the stripe; 0 sends hot segments through the tickets whatever
+ * the hot mode (same results up to rounding - the tests replay all of them on the oracle's plain sequential kernel).
+ * Takes effect from the next epoch call. */
 int mfsgd_grid_set_hot_buffers(mfsgd_grid *g, int32_t n);
 /* How the free-block kernel walks hot segments (takes effect from the next epoch call):
- *   2 (default)  the hot-item WALKER for stripes with one hot item: one wave keeps the item's row in registers for the
- *                whole segment and streams the users' rows through a ring of register slots, requested straight from
- *                HBM 8-32 links ahead (csrc/epoch.hip phase_a_serial) - no ticket, no LDS hand-off, a link is ~130
- *                cycles of dependent issue.  Every straight-line build: fp32 / fp64, k = 64, 128, 192, 256, with or
- *                without the frozen implicit term, no LDS beyond the stripe.  Stripes with several hot items take the
- *                matrix-core pipeline (mode 1) where it can run, else the tickets;
+ *   2 (default)  the hot-item WALKER for stripes with one hot item (csrc/epoch.hip hot_walk): a chain wave keeps the
+ *                item's row in registers for the whole segment and streams the users' rows through a ring of register
+ *                slots, requested straight from HBM a ring ahead - no ticket, no LDS hand-off, a link is ~200 cycles of
+ *                dependent issue, the sequential arithmetic itself; an apply wave a chunk of 64 links behind forms and
+ *                stores the users' rows and moves the frontier the block's other runs wait behind.  Every straight-line
+ *                build: fp32 / fp64, k = 64, 128, 256, with or without the frozen implicit term, no LDS beyond the
+ *                stripe.  Stripes with several hot items take the matrix-core pipeline (mode 1) where it can run, else
+ *                the tickets;
  *   1            the matrix-core pipeline only (phase_a_gram; fp32, k = 64 / 128 / 256, no implicit term, row buffers
  *                in LDS - mfsgd_grid_set_hot_buffers);
  *   0            every rating through the item tickets (as mfsgd_grid_set_hot_buffers(g, 0)).
