@@ -662,26 +662,63 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     load_meta(g, h.t0, h.t1, lane, h.m_item, h.m_tick, h.m_val);
 }
 
+// wave64 sum for the rating chains (walk_run, the walker): wave_sum's tree (same result bit for bit) with the two row
+// broadcasts as single v_add_f32_dpp instructions (hipcc expands the masked broadcast into v_mov 0 / v_mov_dpp / v_add: 4
+// instructions more per rating, on chains where every instruction is ~5 cycles)
+__device__ __forceinline__ float chain_sum(float v)
+{
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    // rows 1 and 3 += the row before, then rows 2 and 3 += row 1 / row 1 + ... : lane 63 ends with (r0 + r1) + (r2 + r3)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double chain_sum(double v) { return wave_sum(v); }
+
 // One rating (numba_methods.py:17-22 without the implicit write-back): error, new user row `pn`, new item row
 // in place, new item bias in place.  The caller settles b_u (it needs `e` only).
+__device__ __forceinline__ float fma_t(float x, float y, float w) { return __builtin_fmaf(x, y, w); }
+__device__ __forceinline__ double fma_t(double x, double y, double w) { return __builtin_fma(x, y, w); }
+// With a = 1 - alpha beta2 (numba_methods.py:21-22):  p' = a p + (alpha e) q,   q' = a q + (alpha e)(p' + z)  - the form the
+// walker uses too: a p and a q do not need the error, so they are formed while the reduction runs, and what follows the
+// error is two dependent fused multiply-adds per factor (the literal form p + alpha (e q - beta2 p) cost 13 vector
+// instructions per rating at k = 128 after the reduction, this one 6).
 template <typename T, int KC, bool HASZ>
 __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q)[KC], T &bi, T rest, T alpha, T beta1,
                                       T beta2, int variant, T (&pn)[KC])
 {
-    T part = 0;
+    const T a = (T)1 - alpha * beta2, a1 = (T)1 - alpha * beta1;
+    T part = 0, ap[KC], aq[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) part += q[c] * (HASZ ? p[c] + zz[c] : p[c]);
-    const T e = rest - bi - wave_sum(part);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) { ap[c] = a * p[c]; aq[c] = a * q[c]; }
+    const T e = rest - bi - chain_sum(part);
+    const T ae = alpha * e;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-        pn[c] = p[c] + alpha * (e * q[c] - beta2 * p[c]);
+        pn[c] = fma_t(ae, q[c], ap[c]);
         const T pu = variant == 0 ? pn[c] : p[c];  // sgd: new p feeds q (numba_methods.py:22); sgd2: old (:53)
-        q[c] = q[c] + alpha * (e * (HASZ ? pu + zz[c] : pu) - beta2 * q[c]);
+        q[c] = fma_t(ae, HASZ ? pu + zz[c] : pu, aq[c]);
     }
-    bi += alpha * (e - beta1 * bi);
+    bi = fma_t(alpha, e, a1 * bi);               // b_i + alpha (e - beta1 b_i)
     return e;
 }
 
+#ifdef MFSGD_WALK_SINK   // A/B: lane 0 alone writes the real word
+#define MF_WALK_STORE(ptr) (*sink_ptr((ptr), ctl, lane))
+#else
+#define MF_WALK_STORE(ptr) (*(ptr))
+#endif
 template <typename T, int KC, bool STAGE, int FAST>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
@@ -712,12 +749,17 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
     // the three-deep prefetch exists to hide (seen in the ISA; netflix shape 30.1 -> 24.9 ms per epoch).
     for (int32_t tc = t0;;) {
     const int32_t te = t1 - tc > 64 ? tc + 64 : t1;
+    // r - b for the 64 ratings at once (fp32: the rating loop then reads it with one v_readlane instead of moving b into
+    // a vector register and subtracting per rating; the value and the order of the subtractions are the same)
+    float m_rb = m_val;
+    if constexpr (sizeof(T) == 4) m_rb = m_val - (float)b;
     for (int32_t t = tc; t < te; ++t) {
         const int32_t slot = t - tc;
         const int32_t ig = __builtin_amdgcn_readlane(m_item, slot);
         const int32_t il = ig - c_base;
         int32_t tk = __builtin_amdgcn_readlane(m_tick, slot);
-        const T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_val), slot));
+        T r = (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_rb), slot));
+        if constexpr (sizeof(T) != 4) r = r - b;
         T bi;
         T *qrow = Q + (int64_t)ig * k;
         PF_T(r0);
@@ -793,7 +835,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #endif
         PF_INC(PF_RATINGS, 1);
         T pn[KC];
-        const T e = sgd_step<T, KC, FAST != 1>(p, zz, q, bi, r - b - bu, alpha, beta1, beta2, variant, pn);
+        const T e = sgd_step<T, KC, FAST != 1>(p, zz, q, bi, r - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
             if constexpr (FAST != 0) {
                 row_put<T, KC>(qs + (size_t)il * k, lane, q);
@@ -804,7 +846,9 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
                     if (f < k) qs[(size_t)il * k + f] = q[c];
                 }
             }
-            *sink_ptr(&bis[il], ctl, lane) = bi;
+            // every lane stores the same value to the same word (a plain store needs no single writer; the select of
+            // sink_ptr cost two vector instructions per rating)
+            MF_WALK_STORE(&bis[il]) = bi;
             LDS_RELEASE();
         } else {
 #pragma unroll
@@ -815,9 +859,9 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
             __hip_atomic_store(&b_i[ig], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes, same word
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
-        __hip_atomic_store(sink_ptr(&tick_done[il], ctl, lane), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&MF_WALK_STORE(&tick_done[il]), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (STAGE) __builtin_amdgcn_s_setprio(0);
-        bu += alpha * (e - beta1 * bu);
+        bu = fma_t(alpha, e, ((T)1 - alpha * beta1) * bu);   // b_u + alpha (e - beta1 b_u)
 #pragma unroll
         for (int c = 0; c < KC; ++c) p[c] = pn[c];
         PF_PIN(p[0]); PF_PIN(p[KC - 1]);
@@ -1236,8 +1280,6 @@ __device__ __forceinline__ void vm_store_so(const V &src, void *sbase, uint32_t 
     else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(src), "s"(sbase) : "memory");   // > 64 bits: hazard nop
 }
-__device__ __forceinline__ float fma_t(float x, float y, float w) { return __builtin_fmaf(x, y, w); }
-__device__ __forceinline__ double fma_t(double x, double y, double w) { return __builtin_fma(x, y, w); }
 template <int N, typename V>
 __device__ __forceinline__ void vm_wait(V &slot)
 {
@@ -1250,28 +1292,6 @@ template <typename T, int KC> __device__ __forceinline__ T row_elem(const typena
 {
     if constexpr (KC == 1) return v; else return v[c];
 }
-
-// wave64 sum for the walker's chain: wave_sum's tree (same result bit for bit) with the two row broadcasts as single
-// v_add_f32_dpp instructions (hipcc expands the masked broadcast into v_mov 0 / v_mov_dpp / v_add: 4 instructions more
-// on a chain where every instruction is ~5 cycles)
-__device__ __forceinline__ float chain_sum(float v)
-{
-    int x;
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false);
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false);
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false);
-    v += __int_as_float(x);
-    // rows 1 and 3 += the row before, then rows 2 and 3 += row 1 / row 1 + ... : lane 63 ends with (r0 + r1) + (r2 + r3)
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                 : "+v"(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ double chain_sum(double v) { return wave_sum(v); }
 
 // ROLE 0 = the CHAIN wave: dot product, reduction, error, the item row's update - the serial part of every link and
 // nothing else; it issues loads only, so its counted waits are exact and all HOT_RING rows stay in flight.  Per chunk of
