@@ -32,6 +32,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 namespace mfprep {  // helpers defined in prep.hip
@@ -637,6 +638,7 @@ __device__ __forceinline__ void load_run(const GridView &g, const RunIdx &x, con
     h.u = __builtin_amdgcn_readfirstlane(x.u);
     h.t0 = __builtin_amdgcn_readfirstlane(x.t0);
     h.t1 = __builtin_amdgcn_readfirstlane(x.t1);
+    if constexpr (FAST != 0) k = 64 * KC;   // the straight-line builds: a constant row width (shifts instead of multiplies)
     const T *prow = P + (int64_t)h.u * k;
     if constexpr (FAST != 0) {
         row_get_agent<T, KC>(prow, lane, h.p);
@@ -692,14 +694,17 @@ __device__ __forceinline__ double fma_t(double x, double y, double w) { return _
 // walker uses too: a p and a q do not need the error, so they are formed while the reduction runs, and what follows the
 // error is two dependent fused multiply-adds per factor (the literal form p + alpha (e q - beta2 p) cost 13 vector
 // instructions per rating at k = 128 after the reduction, this one 6).
-template <typename T, int KC, bool HASZ>
+// VAR: the update order as a compile-time constant (0 sgd, 1 sgd2; -1: `variant` decides at run time - two selects per
+// rating on the dependent chain behind the error)
+template <typename T, int KC, bool HASZ, int VAR = -1>
 __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q)[KC], T &bi, T rest, T alpha, T beta1,
                                       T beta2, int variant, T (&pn)[KC])
 {
+    if constexpr (VAR >= 0) variant = VAR;
     const T a = (T)1 - alpha * beta2, a1 = (T)1 - alpha * beta1;
-    T part = 0, ap[KC], aq[KC];
+    T part = q[0] * (HASZ ? p[0] + zz[0] : p[0]), ap[KC], aq[KC];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) part += q[c] * (HASZ ? p[c] + zz[c] : p[c]);
+    for (int c = 1; c < KC; ++c) part += q[c] * (HASZ ? p[c] + zz[c] : p[c]);
 #pragma unroll
     for (int c = 0; c < KC; ++c) { ap[c] = a * p[c]; aq[c] = a * q[c]; }
     const T e = rest - bi - chain_sum(part);
@@ -719,13 +724,14 @@ __device__ __forceinline__ T sgd_step(const T (&p)[KC], const T (&zz)[KC], T (&q
 #else
 #define MF_WALK_STORE(ptr) (*(ptr))
 #endif
-template <typename T, int KC, bool STAGE, int FAST>
+template <typename T, int KC, bool STAGE, int FAST, int VAR = -1>
 __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, int32_t c_base, T *__restrict__ P,
                                          T *__restrict__ Q, T *__restrict__ b_u, T *__restrict__ b_i, T b, T alpha,
                                          T beta1, T beta2, int variant, int k, int *ctl, int *tick_done, T *qs,
                                          T *bis, int lane, int32_t *err PF_PARAM)
 {
     const int32_t u = h.u, t0 = h.t0, t1 = h.t1;
+    if constexpr (FAST != 0) k = 64 * KC;   // (see load_run)
     PF_T(w0);
     // The head's loads are waited for HERE, by name: hipcc then counts exactly (s_waitcnt vmcnt(N), N = the loads issued
     // since - the heads of the two runs behind this one stay in flight).  Left to the rating loop, the wait became a
@@ -835,7 +841,7 @@ __device__ __forceinline__ void walk_run(const GridView &g, RunHead<T, KC> &h, i
 #endif
         PF_INC(PF_RATINGS, 1);
         T pn[KC];
-        const T e = sgd_step<T, KC, FAST != 1>(p, zz, q, bi, r - bu, alpha, beta1, beta2, variant, pn);
+        const T e = sgd_step<T, KC, FAST != 1, VAR>(p, zz, q, bi, r - bu, alpha, beta1, beta2, variant, pn);
         if (STAGE) {
             if constexpr (FAST != 0) {
                 row_put<T, KC>(qs + (size_t)il * k, lane, q);
@@ -1641,7 +1647,8 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         // The run loop is unrolled three times and the three heads change roles instead of being copied
         // (cur = nxt; nxt = far cost ~16 v_mov per run): the kernel is bound by VALU issue,
         // and this alone took the netflix epoch from 31.9 to 28.7 ms.
-        {
+        auto run_loop = [&](auto var_tag) {
+        constexpr int VAR = decltype(var_tag)::value;
         RunHead<T, KC> h0, h1, h2;
         RunIdx x;
         int32_t j0 = claim();
@@ -1662,7 +1669,7 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
         PF_T(s0);                                                                                                     \
         load_run<T, KC, FAST>(g, x, P, b_u, z, k, lane, LOAD);                                                         \
         PF_T(s1);                                                                                                     \
-        walk_run<T, KC, STAGE, FAST>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,          \
+        walk_run<T, KC, STAGE, FAST, VAR>(g, WALK, c_base, P, Q, b_u, b_i, b, alpha, beta1, beta2, variant, k, ctl,     \
                                      tick_done, qs, bis, lane, err PF_PASS);                                          \
         PF_T(s2);                                                                                                     \
         JN = claim();                                                                                                 \
@@ -1678,6 +1685,13 @@ __device__ __forceinline__ void process_block(const GridView &g, int32_t r, int3
             j0 = ja; j1 = jb; j2 = jc;
         }
 #undef MF_STEP
+        };
+        // the straight-line builds get the update order as a constant (two instantiations of the run loop)
+        if constexpr (FAST != 0) {
+            if (variant == 0) run_loop(std::integral_constant<int, 0>{});
+            else run_loop(std::integral_constant<int, 1>{});
+        } else {
+            run_loop(std::integral_constant<int, -1>{});
         }
     }
     if (lo + RT_CAP < seg_hi || !rest_pass) {   // another chunk or another pass follows: new table,
