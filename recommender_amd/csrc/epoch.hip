@@ -1227,7 +1227,15 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 // (CTL_FMIN), which the apply wave raises after every chunk of 64 links, once the chunk's row stores have drained (one
 // drain of its ring of requested rows per chunk: the apply wave can afford it, the chain wave never drains).
 #ifndef MFSGD_HOT_RING_REGS
-#define MFSGD_HOT_RING_REGS 32   // 64 (a ring of 32 rows at k = 128): netflix shape 21.6 ms per epoch against 21.3
+#define MFSGD_HOT_RING_REGS 32   // 64 (a ring of 32 rows at k = 128): netflix shape 21.6 ms per epoch against 21.3; with the frozen term the
+                                 // ring's p + z slots get twice the registers (16 slots instead of 8: 24.7 -> 22.3 ms, the chain was waiting
+                                 // for HBM), so do 16-byte rows (k = 256: 34.6 -> 32.5 ms)
+#endif
+#ifndef MFSGD_HOT_RING_WIDE
+#define MFSGD_HOT_RING_WIDE 2   // rows of 16 bytes per lane (k = 256 in fp32, 128 in fp64): twice the registers, the same number of slots
+#endif
+#ifndef MFSGD_HOT_RING_Z
+#define MFSGD_HOT_RING_Z 2   // with the frozen term a slot is two rows (p and z): 2 = the same number of slots as without it
 #endif
 #ifndef MFSGD_WALK_FRONT
 // the walker's apply wave publishes the user frontier after every chunk of 64 links (0: once, at the end of the segment:
@@ -1237,7 +1245,10 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 #endif
 template <typename T, int KC, bool HASZ> struct HotRing {   // register slots: MFSGD_HOT_RING_REGS VGPRs of rows at most, 32 slots at most
     static constexpr int regs = KC * (HASZ ? 2 : 1) * (int)(sizeof(T) / 4);
-    static constexpr int value = MFSGD_HOT_RING_REGS / regs >= 32 ? 32 : MFSGD_HOT_RING_REGS / regs >= 16 ? 16 : MFSGD_HOT_RING_REGS / regs >= 8 ? 8 : 4;
+    static constexpr int wanted = MFSGD_HOT_RING_REGS * (HASZ ? MFSGD_HOT_RING_Z : 1) * (KC * (int)sizeof(T) >= 16 ? MFSGD_HOT_RING_WIDE : 1);
+    static constexpr int budget = wanted > 64 ? 64 : wanted;   // of the kernel's 128 registers
+    // (vmcnt counts to 63: at most 32 loads of a ring in flight besides the metadata's, i.e. 16 slots of p + z)
+    static constexpr int value = budget / regs >= 32 && !HASZ ? 32 : budget / regs >= 16 ? 16 : budget / regs >= 8 ? 8 : 4;
 };
 // The walker issues its row loads and waits for them BY HAND (hipcc's wait insertion, fed with a loop that carries 32
 // loads in flight across its back edge and stores it does not see, put `s_waitcnt vmcnt(4)` in front of every link):
