@@ -95,3 +95,30 @@ def test_interleave_stripes_spreads_the_deal_over_the_shards(n, width, world):
     if n % width:
         last = np.flatnonzero(dealt // width == G - 1)
         assert (il[last] // width == G - 1).all()
+
+
+def test_reorder_within_stripes_keeps_the_stripes():
+    """reorder_within_stripes only renumbers inside a stripe: same stripe for every id, still a permutation; "light"
+    reverses the deal's heavy-first order, "spread" alternates the heavy half with the light half."""
+    from recommender_amd.SGDRecommender import reorder_within_stripes
+    rng = np.random.default_rng(5)
+    deg = rng.integers(1, 500, size=1003)
+    width = 100
+    base = balanced_permutation(deg, width)
+    assert reorder_within_stripes(base, width, "heavy") is base
+    for mode in ("light", "shuffle", "spread"):
+        q = reorder_within_stripes(base, width, mode, seed=3)
+        assert sorted(q.tolist()) == list(range(len(deg))), mode
+        assert np.array_equal(q // width, base // width), mode
+    # stripe 0: the deal hands out ids by decreasing degree, so slot order = decreasing degree
+    in0 = np.flatnonzero(base // width == 0)
+    by_slot = in0[np.argsort(base[in0])]
+    assert (np.diff(deg[by_slot]) <= 0).all()
+    light = reorder_within_stripes(base, width, "light")
+    assert (np.diff(deg[in0[np.argsort(light[in0])]]) >= 0).all()
+    spread = reorder_within_stripes(base, width, "spread")
+    s_slot = spread[by_slot] % width                      # heavy half -> even slots, light half -> odd slots
+    half = (len(by_slot) + 1) // 2
+    assert (s_slot[:half] % 2 == 0).all() and (s_slot[half:] % 2 == 1).all()
+    with pytest.raises(ValueError):
+        reorder_within_stripes(base, width, "nope")
