@@ -30,15 +30,14 @@ def bytes_per_update(k, implicit):
 
 
 def kernel_source_hash():
-    """Identifies the build a PMC record in profiles/traffic.json belongs to: sha256 over the kernel sources (the GPU box
-    has no .git).  profiles/collect_traffic.py stores the same hash with every record it writes."""
-    import glob
+    """Identifies the build a PMC record in profiles/traffic.json belongs to: sha256 over the sources of the epoch kernel
+    (csrc/epoch.hip, csrc/common.h - the GPU box has no .git).  profiles/collect_traffic.py stores the same hash with
+    every record it writes."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "recommender_amd", "csrc", "*.hip")) +
-                       glob.glob(os.path.join(ROOT, "recommender_amd", "csrc", "*.h")) +
-                       [os.path.join(ROOT, "include", "mfsgd.h")]):
-        h.update(os.path.basename(path).encode())
+    for name in ("epoch.hip", "common.h"):
+        path = os.path.join(ROOT, "recommender_amd", "csrc", name)
+        h.update(name.encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 

@@ -47,7 +47,7 @@ int mfsgd_dsgd_choose_grid(int64_t n_users, int64_t n_items, int64_t n_train, in
     MF_ARG(ubp_out && ibp_out, "dsgd_choose_grid: null output");
     // one rank's sub-epoch kernel, measured (profiles/r2_dsgd_rank_sim.txt): a stripe's tenure is the chain of its most
     // rated item plus a block transition per row; the ratings matter only when the stripes are few
-    const double block_us = 15.0, rate = 15.0, link_us[2] = {0.12, 0.22};
+    const double block_us = 15.0, rate = 15.0, link_us[2] = {0.09, 0.22};   // hot-item walker, item tickets (dsgd.CHAIN_LINK_US)
     const int64_t ibp_max = std::max<int64_t>(1, (int64_t)(120 * 1024) / ((int64_t)(k + 1) * elem_size + 4));
     const double per = (double)n_train / ((double)world * world);
     const double top = max_item_degree > 0 ? (double)max_item_degree : 0.0016 * (double)n_train;
@@ -57,8 +57,8 @@ int mfsgd_dsgd_choose_grid(int64_t n_users, int64_t n_items, int64_t n_train, in
     for (int64_t cols = std::max<int64_t>(cmin, 8); cols <= std::min<int64_t>(n_cus, std::max<int64_t>(1, n_items / world)); cols += 4) {
         const int64_t rows = std::min<int64_t>(cols + std::max<int64_t>(1, cols / 8), std::max<int64_t>(1, n_users / world));
         const int64_t ibp = (n_items + cols * world - 1) / (cols * world);
-        const bool piped = (k == 64 || k == 128) && elem_size == 4 &&
-                           mfsgd_lds_bytes((int32_t)ibp, (int32_t)rows, k, 4, 2) <= 160 * 1024;
+        const bool piped = (k == 64 || k == 128 || k == 256) && elem_size == 4 &&
+                           mfsgd_lds_bytes((int32_t)ibp, (int32_t)rows, k, 4, 0) <= 160 * 1024;   // where the walker runs
         const double chain = top / world * link_us[piped ? 0 : 1];
         const double t = std::max(chain + rows * block_us, per / (cols * rate));
         if (best_t < 0 || t < best_t - 1e-9) { best_t = t; best_rows = rows; best_cols = cols; }
