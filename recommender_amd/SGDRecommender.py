@@ -126,9 +126,10 @@ HOT_RATING_COST = 0.8       # a rating on the matrix-core pipeline against one o
                             # it (netflix shape, k = 128, swept 0.25 .. 1.0: 25.4 ms per epoch at 0.25, 24.1 at 0.7 - 0.85,
                             # 24.4 at 1.0; the pipeline's own time per rating is a third of the ticket path's, but the
                             # users of a hot segment hold their other runs back until the pipeline has passed them)
-WALKER_RATING_COST = 0.3    # the same for the hot-item walker (two waves instead of six, the frontier moves every 64 links):
-                            # netflix shape, k = 128: 21.0 ms per epoch at 0.1, 21.1 at 0.2, 21.3 at 0.3, 21.6 at 0.5, 22.1 at
-                            # 0.8; ML-25M shape 9.05 at 0.1, 8.93 at 0.3, 8.79 at 0.8; frozen term 28.2 at 0.3, 28.1 at 0.8
+WALKER_RATING_COST = 0.15   # the same for the hot-item walker (two waves instead of six, the frontier moves every 64 links),
+                            # final build (the apply wave 16 links behind the chain): netflix shape, k = 128: 17.87-17.89 ms per
+                            # epoch at 0.05-0.1, 17.85-17.91 at 0.15, 17.92 at 0.2, 18.03 at 0.3, 18.07 at 0.35; ML-25M shape
+                            # 6.93 at 0.1-0.15, 6.94-6.97 at 0.3, 7.04 at 0.4
 
 
 def item_costs(deg, Gr, Gc, pipeline_runs, hot_items=1, weight=None, hot_min=64, walker=False):

@@ -1237,6 +1237,9 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 #ifndef MFSGD_HOT_RING_Z
 #define MFSGD_HOT_RING_Z 2   // with the frozen term a slot is two rows (p and z): 2 = the same number of slots as without it
 #endif
+#ifndef MFSGD_WALK_SUB
+#define MFSGD_WALK_SUB 16
+#endif
 #ifndef MFSGD_WALK_FRONT
 // the walker's apply wave publishes the user frontier after every chunk of 64 links (0: once, at the end of the segment:
 // netflix shape 24.1 ms per epoch against 22.1, frozen 31.2 against 28.1, ML-25M 9.22 against 8.79; 2: every 32 links:
@@ -1324,6 +1327,8 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
 {
     constexpr int D = HotRing<T, KC, HASZ>::value;   // divides 64
     constexpr int L = HASZ ? 2 : 1;                  // loads per link
+    constexpr int SUB = MFSGD_WALK_SUB, NS = 64 / SUB;   // the chain wave's turn word counts groups of SUB links
+    static_assert(SUB == 8 || SUB == 16 || SUB == 32 || SUB == 64, "MFSGD_WALK_SUB divides 64");
     typedef typename RowReg<T, KC>::type Row;
     const int lane = threadIdx.x & 63;
     T *qrow = qs + (size_t)(hot_item - c_base) * k;
@@ -1385,15 +1390,6 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
                 if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-        } else {
-            for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN], __ATOMIC_RELAXED,
-                                                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) <= chunk; ++spins) {
-                if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            LDS_ACQUIRE();
-            evec = eb[lane];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(evec));
         }
         // the chunk is straight-line code: every lane index below is a constant, every load unconditional
 #pragma unroll
@@ -1403,6 +1399,19 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
             // ROLE 1 also has a store per link in the queue: counting loads only makes its wait early, never late
             if constexpr (HASZ) { vm_wait<(DD - 1) * L>(rz[s]); asm volatile("" : "+v"(rp[s])); }
             else vm_wait<(DD - 1) * L>(rp[s]);
+            if constexpr (ROLE == 1) {
+                // the errors arrive MFSGD_WALK_SUB links at a time: this wave follows the chain that closely
+                if (li % SUB == 0 && li < nb) {
+                    for (int spins = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_TOKEN], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP)) <= chunk * NS + li / SUB; ++spins) {
+                        if (spins >= SPIN_TICKET_MAX) { atomicOr(err, 4); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    LDS_ACQUIRE();
+                    evec = eb[lane];
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(evec));
+                }
+            }
             if (li < nb) {                                       // wave-uniform
                 T ap[KC], aq[KC], pn[KC];
 #pragma unroll
@@ -1440,6 +1449,13 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
                     vm_store_so(out, P, (uint32_t)__builtin_amdgcn_readlane(offA, li) + lane_off);
                 }
             }
+            if constexpr (ROLE == 0 && SUB < 64) {
+                if ((li + 1) % SUB == 0 && li != 63 && li < nb) {
+                    LDS_RELEASE();
+                    __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), chunk * NS + (li + 1) / SUB, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
 #if MFSGD_WALK_FRONT >= 2
             if constexpr (ROLE == 1) {
                 if (li == 31 && nb > 32) {   // half-chunk publish (see the end of the chunk)
@@ -1457,7 +1473,7 @@ __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int3
         }
         if constexpr (ROLE == 0) {
             LDS_RELEASE();
-            __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sink_ptr(&ctl[CTL_TOKEN], ctl, lane), (chunk + 1) * NS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             // the users' biases (numba_methods.py:19); the error buffer is free again
             if (lane < nb) untracked_store(&b_u[ujA], buA + alpha * (evec - beta1 * buA));
