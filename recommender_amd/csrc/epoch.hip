@@ -434,7 +434,8 @@ constexpr int CTL_WORDS = 16 + 128 + 5 * MAXSEG + 4;  // 16 control words + 128 
 // is), CTL_FRONT + s = batches published, CTL_FUSER + s = "segment s is done for every user <= this" (0x7fffffff: all)
 // CTL_BND + p, p = 0 .. MAXSEG + 1: run ranges of the block's passes (hot segments, then the rest; process_block)
 // CTL_FMIN: a lower bound of the minimum of all CTL_FUSER words, only ever raised (atomic max): what the rest of the
-// block waits behind
+// block waits behind.  The walker (one segment) uses the same words: CTL_TOKEN = groups of MFSGD_WALK_SUB links whose chain
+// is done, CTL_TOKEN + 1 = "the apply wave has its copy of the item's row", CTL_FRONT = chunks of 64 links applied
 enum { CTL_COL = 0, CTL_ROW = 1, CTL_RUN = 2, CTL_REMAIN = 3, CTL_FMIN = 4, CTL_SINK = 16, CTL_TOKEN = 16 + 128,
        CTL_FRONT = CTL_TOKEN + MAXSEG, CTL_FUSER = CTL_FRONT + MAXSEG, CTL_BND = CTL_FUSER + MAXSEG,
        CTL_HOT = CTL_BND + MAXSEG + 2 };   // CTL_HOT + s: hot item s of the stripe in tenure (global id, -1: none)
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ void phase_a_gram(const GridView &g, int32_t run_lo, 
 #define MFSGD_HOT_RING_Z 2   // with the frozen term a slot is two rows (p and z): 2 = the same number of slots as without it
 #endif
 #ifndef MFSGD_WALK_SUB
-#define MFSGD_WALK_SUB 16
+#define MFSGD_WALK_SUB 16   // links per hand-over from the walker's chain wave to its apply wave (divides 64; see hot_walk)
 #endif
 #ifndef MFSGD_WALK_FRONT
 // the walker's apply wave publishes the user frontier after every chunk of 64 links (0: once, at the end of the segment:
@@ -1314,10 +1315,13 @@ template <typename T, int KC> __device__ __forceinline__ T row_elem(const typena
 }
 
 // ROLE 0 = the CHAIN wave: dot product, reduction, error, the item row's update - the serial part of every link and
-// nothing else; it issues loads only, so its counted waits are exact and all HOT_RING rows stay in flight.  Per chunk of
-// 64 links it leaves the 64 errors in LDS (ebuf) and bumps CTL_TOKEN.
-// ROLE 1 = the APPLY wave, a chunk behind: with the errors known it runs the item row forward once more (the same
-// operations on the same inputs: the same rows q_j) and forms, stores and publishes the users' new rows and biases.
+// nothing else; it issues loads only, so its counted waits are exact and all HOT_RING rows stay in flight.  It leaves
+// the errors in LDS (ebuf, 64 per chunk) and raises its turn word CTL_TOKEN after every MFSGD_WALK_SUB links
+// (CTL_TOKEN = groups of MFSGD_WALK_SUB links done, counted over the whole segment).
+// ROLE 1 = the APPLY wave, MFSGD_WALK_SUB links behind: with the errors known it runs the item row forward once more (the
+// same operations on the same inputs: the same rows q_j) and forms, stores and publishes the users' new rows and biases.
+// (Until the last step of round 3 it waited for whole chunks: ML-25M shape, 115-link segments, 7.31 -> 6.95 ms per epoch;
+// 8 links: no better.)
 // One update with a = 1 - alpha beta2 (numba_methods.py:21-22):  p' = a p + (alpha e) q,   q' = a q + (alpha e)(p' + z).
 template <typename T, int KC, bool HASZ, int ROLE>
 __device__ __forceinline__ void hot_walk(const GridView &g, int32_t run_lo, int32_t t_lo, int32_t nh, int32_t hot_item,
