@@ -18,6 +18,8 @@ rule it implements is the same FPSGD invariant (RayBlockScheduler.py:50-62) one 
 The plan (who holds what when) is pure Python and runs anywhere; the compute step is a callable, so the
 CPU tests drive the same ring with a CPU block kernel of their own under gloo.
 """
+import os
+import sys
 import time
 
 import numpy as np
@@ -86,11 +88,20 @@ def ring_epoch(plan, rank, Q, b_i, compute, dist=None):
 
 def gather_items(plan, rank, Q, b_i, dist):
     """After a whole epoch shard q is current on rank q: everyone fetches every shard (evaluation only)."""
+    staged = getattr(Q, "is_cuda", False) and dist.get_backend() == "gloo"   # rehearsal on one GPU box (see ring_epoch)
     for q in range(plan.world):
         a0, a1 = plan.item_range(q)
         if a1 > a0:
-            dist.broadcast(Q[a0:a1], src=q)
-            dist.broadcast(b_i[a0:a1], src=q)
+            if staged:
+                hq, hb = Q[a0:a1].cpu(), b_i[a0:a1].cpu()
+                dist.broadcast(hq, src=q)
+                dist.broadcast(hb, src=q)
+                if rank != q:
+                    Q[a0:a1].copy_(hq)
+                    b_i[a0:a1].copy_(hb)
+            else:
+                dist.broadcast(Q[a0:a1], src=q)
+                dist.broadcast(b_i[a0:a1], src=q)
 
 
 # what profiles/dsgd_rank_sim.py measured for ONE rank's sub-epoch kernel on an MI355X (netflix shape, k = 128)
@@ -237,6 +248,12 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
 
     train, test, U, I, k = data
     n_train_total = int(train.shape[0])
+    verbose = bool(os.environ.get("MFSGD_BENCH_VERBOSE"))
+
+    def note(msg):      # progress on stderr (rehearsals: a silent minute looks like a hang)
+        if verbose:
+            print(f"[dsgd bench rank {rank}] {msg} (+{time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
     if args.grid:
         Gr, Gc = (int(x) for x in args.grid.split(","))
         ubp, ibp = -(-U // Gr), -(-I // Gc)
@@ -249,12 +266,14 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     # users' ratings, P rows and biases (RankWorker).  A real job hands each rank its stripe and nothing else.
     du = torch.bincount(train[:, 0].long(), minlength=U).cpu().numpy()
     di = torch.bincount(train[:, 1].long(), minlength=I).cpu().numpy()
+    note(f"grid: {ubp} users x {ibp} items per block")
     plan0 = DSGDPlan(U, I, world, ubp, ibp)
     rows = max(1, -(-(plan0.user_range(0)[1] - plan0.user_range(0)[0]) // ubp))
     cost = item_costs(di, rows, plan0.Gc, pipeline_fits(I, ibp, rows, k, args.hot_buffers), 1,
                       None if args.hot_cost < 0 else args.hot_cost, walker=True)
     rp = torch.from_numpy(balanced_permutation(du, ubp).astype(np.int32)).cuda()
     cp = torch.from_numpy(interleave_stripes(balanced_permutation(di, ibp, cost), ibp, world).astype(np.int32)).cuda()
+    note("permutations done")
     lib = _abi.lib()
     for t in (train, test):
         _abi.check(lib.mfsgd_hip_remap(_abi.ptr(t), int(t.shape[0]), 3, _abi.ptr(rp), _abi.ptr(cp), U, I, _abi.stream_ptr()))
@@ -271,9 +290,12 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     del train_l, test_l
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t0
+    note(f"rank worker built: {[ (g.info.Gr, g.info.Gc) for g in w.grids ]}")
     rm0 = w.errors(dist)                         # before any training (the warm-up epochs train too)
+    note(f"rmse before: {rm0}")
     for _ in range(args.warmup):
         w.epoch(dist)
+        note("warm-up epoch done")
     w.status()
     dist.barrier()
     torch.cuda.synchronize()
@@ -281,6 +303,7 @@ def bench_main(args, rank, world, data, bytes_per_update, hbm_peak, hp):
     for _ in range(args.steps):
         w.epoch(dist)
     torch.cuda.synchronize()
+    note("timed epochs done")
     dist.barrier()
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     if dist.get_backend() == "gloo":
