@@ -97,6 +97,7 @@ struct SchedView {
 
 constexpr int SPIN_TICKET_MAX = 1 << 22;  // every spin is bounded: a stuck wave flags the run and moves on
 constexpr int SPIN_LOCK_SWEEPS = 1 << 20;
+constexpr int META_PAD = 64;   // words behind the last rating in item / tick / val: load_meta may read (and ignore) up to 63 past a run's end
 constexpr int MAX_PASSES_PER_LAUNCH = 200;   // visit counts live in one byte per user stripe (row_done in k_epoch_free)
 #ifndef TICKET_NAP
 #define TICKET_NAP 3   // s_sleep units (64 clocks) a waiter sleeps per hand-off in front of it
@@ -619,10 +620,16 @@ __device__ __forceinline__ void run_index(const GridView &g, int32_t j, RunIdx &
 __device__ __forceinline__ void load_meta(const GridView &g, int32_t t, int32_t t1, int lane, int32_t &m_item,
                                           int32_t &m_tick, float &m_val)
 {
-    const int32_t tt = t + lane < t1 ? t + lane : t1 - 1;
-    m_item = g.item[tt];
-    m_tick = g.tick[tt];
-    m_val = g.val[tt];
+    // t and t1 are wave-uniform: scalar base + a lane offset below 64 - one v_min and one shift per run instead of a
+    // 64-bit vector address per array (netflix shape 17.87 -> 17.72 ms per epoch, ML-25M 6.94 -> 6.85).  The same for the
+    // user's row was NOT faster (its address as an opaque scalar: 18.8 ms; the stores with a scalar base: 17.9).
+    // An empty run (the one behind a table's last: t == t1) reads word t + 63, which no one uses: the three arrays are
+    // allocated with META_PAD words behind their last rating (mfsgd_grid_create_opt); guarding that case in here instead
+    // cost more than the change gains (18.1 ms).
+    const uint32_t off = (uint32_t)min((int32_t)lane, t1 - 1 - t) & 63u;
+    m_item = (g.item + t)[off];
+    m_tick = (g.tick + t)[off];
+    m_val = (g.val + t)[off];
 }
 
 // Issues the loads of a run's head; nothing here waits, so a caller can keep two runs in flight behind the
@@ -2299,7 +2306,7 @@ static int grid_build(const int32_t *samples, int64_t n, int32_t stride, int64_t
     G->info.user_unique = 1;
     auto dalloc = [&](auto **p, size_t count) { return hipMalloc((void **)p, (count ? count : 1) * sizeof(**p)); };
     MF_HIP(dalloc(&G->blk_run_ptr, (size_t)nb + 1));
-    MF_HIP(dalloc(&G->item, (size_t)n)); MF_HIP(dalloc(&G->tick, (size_t)n)); MF_HIP(dalloc(&G->val, (size_t)n));
+    MF_HIP(dalloc(&G->item, (size_t)n + META_PAD)); MF_HIP(dalloc(&G->tick, (size_t)n + META_PAD)); MF_HIP(dalloc(&G->val, (size_t)n + META_PAD));
     MF_HIP(dalloc(&G->col_order, (size_t)Gc));
     MF_HIP(dalloc(&G->col_hot, (size_t)Gc * MAXSEG)); MF_HIP(dalloc(&G->blk_hot_cnt, (size_t)nb));
     MF_HIP(dalloc(&G->blk_seg_cnt, (size_t)nb * MAXSEG)); MF_HIP(dalloc(&G->blk_free_runs, (size_t)nb));
